@@ -1,0 +1,177 @@
+"""CPU: pin oracle/sg_oracle.c against the fixtures captured from the reference
+(tools/gen_golden.py).  The reference has no tests of its own for this path
+(SURVEY.md section 4), so these captures are the pin."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from helpers import assert_close, load
+
+KIND = {"mlp": orc.KIND_MLP, "split": orc.KIND_SPLIT}
+
+
+def dims_of(m):
+    return orc.dims(KIND[m["kind"]], m["O"], m["A"], m["H"], m["num_feet"])
+
+
+POLICY_CASES = ["policy_mlp_tiny", "policy_mlp_northstar", "policy_mlp_hopper",
+                "policy_split_hopper", "policy_split_laikago", "policy_split_tiny"]
+
+
+@pytest.mark.parametrize("name", POLICY_CASES)
+def test_policy_forward_act_evaluate(name):
+    g = load(name)
+    d = dims_of(g["meta"])
+    assert orc.policy_num_params(d) == g["params"].size
+    value, mean, logstd = orc.policy_forward(d, g["params"], g["obs"])
+    assert_close(mean, g["mean"], what="mean")
+    assert_close(np.exp(logstd), g["std"], what="std")
+    assert_close(value, g["get_value"], what="value")
+    v, a, lp = orc.policy_act(d, g["params"], g["obs"], g["noise"])
+    assert_close(v, g["act_value"], what="act value")
+    assert_close(a, g["act_action"], what="act action")
+    assert_close(lp, g["act_logp"], what="act logp")
+    v, a, lp = orc.policy_act(d, g["params"], g["obs"], None)
+    assert_close(a, g["det_action"], what="det action")
+    assert_close(lp, g["det_logp"], what="det logp")
+    v, lp, ent = orc.policy_evaluate(d, g["params"], g["obs"], g["eval_action"])
+    assert_close(v, g["eval_value"], what="eval value")
+    assert_close(lp, g["eval_logp"], what="eval logp")
+    assert_close(ent, g["eval_entropy"], what="entropy")
+
+
+@pytest.mark.parametrize("use_gae", [1, 0])
+@pytest.mark.parametrize("proper", [1, 0])
+def test_compute_returns(use_gae, proper):
+    g = load("gae")
+    ret, vp = orc.compute_returns(g["rewards"][..., 0], g["value_preds"][..., 0], g["masks"][..., 0],
+                                  g["bad_masks"][..., 0], g["next_value"][:, 0], use_gae, 0.99, 0.95, proper)
+    T = g["rewards"].shape[0]
+    want = g[f"returns_gae{use_gae}_proper{proper}"][..., 0]
+    # the GAE branch never writes returns[T] (a2c/storage.py:110-120); compare the slots it defines
+    upto = T if use_gae else T + 1
+    assert_close(ret[:upto], want[:upto], rtol=1e-5, what="returns")
+    assert_close(vp, g[f"value_preds_gae{use_gae}_proper{proper}"][..., 0], what="value_preds")
+
+
+def test_running_mean_std():
+    g = load("rms")
+    st = [0.0, 1.0, 1e-4]
+    for x, want in zip(g["xs"], g["states"]):
+        st = orc.rms_update(st, x)
+        assert_close(st, want, rtol=1e-6, what="rms state")
+
+
+PPO_CASES = ["ppo_mlp_tiny", "ppo_mlp_northstar", "ppo_mlp_onestep", "ppo_split_hopper",
+             "ppo_split_laikago"]
+
+
+def ppo_cfg_of(m):
+    return orc.ppo_cfg(m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], m["value_loss_coef"],
+                       m["entropy_coef"], m["lr"], m["eps"], m["max_grad_norm"], True)
+
+
+@pytest.mark.parametrize("name", PPO_CASES)
+def test_ppo_update(name):
+    g = load(name)
+    m = g["meta"]
+    d = dims_of(m)
+    adv = orc.advantages(g["returns"][:-1], g["value_preds"][:-1])
+    assert_close(adv, g["advantages"], rtol=1e-5, what="advantages")
+    params = g["params0"].copy()
+    adam = orc.AdamState(params.size)
+    losses = orc.ppo_update(d, params, adam, ppo_cfg_of(m), g["obs"], g["actions"],
+                            g["value_preds"][..., 0], g["returns"][..., 0],
+                            g["action_log_probs"][..., 0], g["perms"])
+    assert_close(losses, g["losses"], what="ppo losses")
+    assert_close(adam.m, g["adam_m"], rtol=1e-3, atol=1e-7, what="adam m")
+    assert_close(adam.v, g["adam_v"], rtol=1e-3, atol=1e-10, what="adam v")
+    assert_close(params, g["params1"], what="params after update")
+    # the update must actually have moved the parameters by more than the tolerance
+    assert np.max(np.abs(g["params1"] - g["params0"])) > 1e-4
+
+
+DISC_CASES = ["disc_tiny", "disc_northstar", "disc_hopper", "disc_single_batch"]
+
+
+@pytest.mark.parametrize("name", DISC_CASES)
+def test_disc_update(name):
+    g = load(name)
+    m = g["meta"]
+    params = g["params0"].copy()
+    adam = orc.AdamState(params.size)
+    for ep in range(m["epochs"]):
+        losses, n_d = orc.disc_update(m["F"], m["Hd"], params, adam, g["expert"], g["obs_feat"], m["B"],
+                                      g[f"expert_perm{ep}"], g[f"policy_perm{ep}"], g[f"alpha{ep}"])
+        assert n_d == int(g[f"n_steps{ep}"])
+        assert_close(losses, g[f"losses{ep}"], what=f"disc losses ep{ep}")
+        assert_close(params, g[f"params_after{ep}"], what=f"disc params ep{ep}")
+
+
+@pytest.mark.parametrize("name", ["relabel_tiny", "relabel_northstar"])
+def test_relabel(name):
+    g = load(name)
+    m = g["meta"]
+    rew, ret = orc.disc_predict_reward(m["F"], m["Hd"], g["params"], g["obs_feat0"][1], m["gamma"],
+                                       g["masks0"][0], float(g["offset0"]))
+    assert_close(rew, g["raw_reward0"], what="raw reward")
+    d_ret, rms = None, [0.0, 1.0, 1e-4]
+    for call in range(2):
+        rewards, d_ret, rms = orc.relabel(m["F"], m["Hd"], g["params"], g[f"obs_feat{call}"],
+                                          g[f"masks{call}"][..., 0], m["gamma"], float(g[f"offset{call}"]),
+                                          d_ret, rms)
+        assert_close(rewards, g[f"rewards{call}"][..., 0], what="relabelled rewards")
+        assert_close(d_ret, g[f"d_returns{call}"][:, 0], what="D.returns")
+        assert_close(rms, g[f"rms{call}"], rtol=1e-5, what="ret_rms")
+
+
+@pytest.mark.parametrize("name", ["iter_mlp", "iter_split"])
+def test_full_iteration(name):
+    """a2c/main_gail_dyn_ppo.py:239-304 restated with oracle calls, 2 outer iterations."""
+    g = load(name)
+    m = g["meta"]
+    d = dims_of(m)
+    T, N, F, Hd, B = m["T"], m["N"], m["F"], m["Hd"], m["B"]
+    pi = g["pi_params0"].copy()
+    dp = g["d_params0"].copy()
+    pi_adam, d_adam = orc.AdamState(pi.size), orc.AdamState(dp.size)
+    cfg = orc.ppo_cfg(0.2, m["ppo_epoch"], m["num_mini_batch"], 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
+    obs = np.zeros((T + 1, N, m["O"]), np.float32)
+    obs_feat = np.zeros((T + 1, N, F), np.float32)
+    masks = np.ones((T + 1, N), np.float32)
+    bad = np.ones((T + 1, N), np.float32)
+    obs[0] = g["obs0"]
+    d_ret, rms = None, [0.0, 1.0, 1e-4]
+    for j in range(m["iters"]):
+        actions = np.zeros((T, N, m["A"]), np.float32)
+        logp = np.zeros((T, N), np.float32)
+        vp = np.zeros((T + 1, N), np.float32)
+        for t in range(T):
+            v, a, lp = orc.policy_act(d, pi, obs[t], g[f"it{j}_noise"][t])
+            actions[t], logp[t], vp[t] = a, lp[:, 0], v[:, 0]
+            obs[t + 1] = g[f"it{j}_env_obs"][t]
+            obs_feat[t + 1] = g[f"it{j}_env_feat"][t]
+            masks[t + 1] = g[f"it{j}_env_masks"][t][:, 0]
+            bad[t + 1] = g[f"it{j}_env_bad"][t][:, 0]
+        assert_close(actions, g[f"it{j}_actions"], what="rollout actions")
+        assert_close(logp, g[f"it{j}_action_log_probs"][..., 0], what="rollout logp")
+        nv = orc.policy_forward(d, pi, obs[T])[0]
+        assert_close(nv, g[f"it{j}_next_value"], what="next_value")
+        for ep in range(m["gail_epoch"]):
+            losses, _ = orc.disc_update(F, Hd, dp, d_adam, g["expert"], obs_feat, B,
+                                        g[f"it{j}_d{ep}_expert_perm"], g[f"it{j}_d{ep}_policy_perm"],
+                                        g[f"it{j}_d{ep}_alpha"])
+            assert_close(losses, g[f"it{j}_d_losses"][ep], what="D losses")
+        assert_close(dp, g[f"it{j}_d_params"], what="D params")
+        r_sa = orc.alive_bonus(masks, T, N, m["gail_tar_length"])
+        assert_close(r_sa, g[f"it{j}_r_sa"], rtol=1e-9, what="r_sa")
+        rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, m["gamma"], -r_sa, d_ret, rms)
+        assert_close(rewards, g[f"it{j}_rewards"][..., 0], what="rewards")
+        assert_close(rms, g[f"it{j}_rms"], rtol=1e-5, what="rms")
+        ret, vp = orc.compute_returns(rewards, vp, masks, bad, nv[:, 0], 1, m["gamma"], m["gae_lambda"], 1)
+        assert_close(ret[:T], g[f"it{j}_returns"][:T, :, 0], what="returns")
+        losses = orc.ppo_update(d, pi, pi_adam, cfg, obs, actions, vp, ret, logp, g[f"it{j}_ppo_perms"])
+        assert_close(losses, g[f"it{j}_ppo_losses"], what="ppo losses")
+        assert_close(pi, g[f"it{j}_pi_params"], what="pi params")
+        # after_update a2c/storage.py:96-101
+        obs[0], obs_feat[0], masks[0], bad[0] = obs[T], obs_feat[T], masks[T], bad[T]

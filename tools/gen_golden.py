@@ -1,0 +1,382 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the dev container.
+
+Dev-only: imports /root/reference (via tools/ref_import.py stand-in modules for
+gym/pybullet), drives the reference's own Policy / SplitPolicy / RolloutStorage /
+PPO / Discriminator / RunningMeanStd on seeded inputs, records every RNG-derived
+artefact the hot path draws (torch.randperm / torch.rand / sampling noise) and
+dumps inputs + outputs as small fixtures.  The fixtures (data only) are
+committed; this script documents how they were made.  Re-run:
+    python tools/gen_golden.py
+The call sequences mirror a2c/main_gail_dyn_ppo.py:239-304 (a2c/ =
+third_party/a2c_ppo_acktr/).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+ns = import_reference()
+torch.set_num_threads(1)  # a2c/main_gail_dyn_ppo.py:64
+
+# ---------------------------------------------------------------- RNG capture
+_REC = []
+_randperm, _rand = torch.randperm, torch.rand
+
+
+def _rp(n, *a, **k):
+    r = _randperm(n, *a, **k)
+    _REC.append(("randperm", r.clone().numpy()))
+    return r
+
+
+def _rd(*a, **k):
+    r = _rand(*a, **k)
+    _REC.append(("rand", r.clone().numpy()))
+    return r
+
+
+torch.randperm, torch.rand = _rp, _rd
+
+
+def flat_params(module):
+    return np.concatenate([v.detach().numpy().reshape(-1) for v in module.state_dict().values()]).astype(np.float32)
+
+
+def make_policy(kind, O, A, H, f, seed):
+    torch.manual_seed(seed)
+    if kind == "mlp":
+        p = ns.Policy((O,), ns.Box(shape=(A,)), base_kwargs={"recurrent": False, "hidden_size": H})
+    else:
+        p = ns.SplitPolicy((O,), ns.Box(shape=(A,)), base_kwargs={"hidden_size": H, "num_feet": f})
+    # the init makes the mean head tiny (weights/50 or gain 0.02); bump everything a little so
+    # fixtures exercise non-trivial means / state-dependent logstd and non-zero biases
+    with torch.no_grad():
+        for q in p.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    return p
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def meta(**kw):
+    return np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ A. policy
+def gen_policy(name, kind, O, A, H, f, n, seed):
+    p = make_policy(kind, O, A, H, f, seed)
+    params = flat_params(p)
+    torch.manual_seed(seed + 1)
+    obs = torch.randn(n, O)
+    hxs, masks = torch.zeros(n, 1), torch.ones(n, 1)
+    with torch.no_grad():
+        torch.manual_seed(seed + 2)
+        value, action, logp, _ = p.act(obs, hxs, masks)
+        torch.manual_seed(seed + 2)
+        noise = torch.randn(n, A)  # same stream torch.normal(mean,std) consumed
+        v_det, a_det, lp_det, _ = p.act(obs, hxs, masks, deterministic=True)
+        # check noise reproduces the sampled action: action = mean + std*noise
+        value2, feat, _ = p.base(obs, hxs, masks)
+        dist = p.dist(feat)
+        recon = dist.mean + dist.stddev * noise
+        if not torch.allclose(recon, action, rtol=0, atol=1e-6):
+            noise = (action - dist.mean) / dist.stddev
+        torch.manual_seed(seed + 3)
+        act_eval = action + 0.3 * torch.randn(n, A)
+        ev_value, ev_logp, ev_ent, _ = p.evaluate_actions(obs, hxs, masks, act_eval)
+        gv = p.get_value(obs, hxs, masks)
+    save(name, meta=meta(kind=kind, O=O, A=A, H=H, num_feet=f), params=params, obs=obs.numpy(),
+         noise=noise.numpy(), act_value=value.numpy(), act_action=action.numpy(),
+         act_logp=logp.numpy(), det_action=a_det.numpy(), det_logp=lp_det.numpy(),
+         mean=dist.mean.numpy(), std=dist.stddev.numpy(), eval_action=act_eval.numpy(),
+         eval_value=ev_value.numpy(), eval_logp=ev_logp.numpy(), eval_entropy=np.float32(ev_ent.item()),
+         get_value=gv.numpy())
+
+
+# --------------------------------------------------------------------- B. GAE
+def fill_rollout(ro, T, N, O, A, F, seed, p_done=0.1, p_bad=0.05):
+    g = torch.Generator().manual_seed(seed)
+    ro.obs.copy_(torch.randn(T + 1, N, O, generator=g))
+    if F:
+        ro.obs_feat.copy_(torch.randn(T + 1, N, F, generator=g))
+    ro.actions.copy_(torch.randn(T, N, A, generator=g))
+    ro.rewards.copy_(torch.randn(T, N, 1, generator=g))
+    ro.value_preds.copy_(torch.randn(T + 1, N, 1, generator=g))
+    ro.action_log_probs.copy_(torch.randn(T, N, 1, generator=g))
+    ro.masks.copy_((torch.rand(T + 1, N, 1, generator=g) > p_done).float())
+    ro.bad_masks.copy_((torch.rand(T + 1, N, 1, generator=g) > p_bad).float())
+
+
+def gen_gae():
+    T, N, O, A = 12, 6, 3, 2
+    out = {}
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, 0)
+    fill_rollout(ro, T, N, O, A, 0, 11)
+    nv = torch.randn(N, 1, generator=torch.Generator().manual_seed(12))
+    out.update(rewards=ro.rewards.numpy().copy(), value_preds=ro.value_preds.numpy().copy(),
+               masks=ro.masks.numpy().copy(), bad_masks=ro.bad_masks.numpy().copy(),
+               next_value=nv.numpy(), gamma=np.float32(0.99), lam=np.float32(0.95))
+    vp0, ret0 = ro.value_preds.clone(), ro.returns.clone()
+    for use_gae in (1, 0):
+        for proper in (1, 0):
+            ro.value_preds.copy_(vp0)
+            ro.returns.copy_(ret0)
+            ro.compute_returns(nv, bool(use_gae), 0.99, 0.95, bool(proper))
+            out[f"returns_gae{use_gae}_proper{proper}"] = ro.returns.numpy().copy()
+            out[f"value_preds_gae{use_gae}_proper{proper}"] = ro.value_preds.numpy().copy()
+    save("gae", **out)
+
+
+# --------------------------------------------------------------------- C. PPO
+def rollout_from_policy(p, T, N, O, A, F, seed, kind):
+    """Fill a RolloutStorage the way the main loop would (act -> insert), synthetic env."""
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, F)
+    g = torch.Generator().manual_seed(seed)
+    ro.obs[0].copy_(torch.randn(N, O, generator=g))
+    for step in range(T):
+        with torch.no_grad():
+            value, action, logp, hxs = p.act(ro.obs[step], ro.recurrent_hidden_states[step], ro.masks[step])
+        obs = torch.randn(N, O, generator=g)
+        reward = torch.randn(N, 1, generator=g)
+        masks = (torch.rand(N, 1, generator=g) > 0.08).float()
+        bad = (torch.rand(N, 1, generator=g) > 0.03).float()
+        feat = torch.randn(N, F, generator=g) if F else None
+        ro.insert(obs, hxs, action, logp, value, reward, masks, bad, feat)
+    return ro
+
+
+def perturb(p, scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for q in p.parameters():
+            q.add_(scale * torch.randn(q.shape, generator=g))
+
+
+def rollout_arrays(ro):
+    return dict(obs=ro.obs.numpy().copy(), obs_feat=ro.obs_feat.numpy().copy(),
+                actions=ro.actions.numpy().copy(), rewards=ro.rewards.numpy().copy(),
+                value_preds=ro.value_preds.numpy().copy(), returns=ro.returns.numpy().copy(),
+                action_log_probs=ro.action_log_probs.numpy().copy(), masks=ro.masks.numpy().copy(),
+                bad_masks=ro.bad_masks.numpy().copy())
+
+
+def gen_ppo(name, kind, O, A, H, f, T, N, E, M, clip, ecoef, lr, seed, pert=0.02):
+    p = make_policy(kind, O, A, H, f, seed)
+    torch.manual_seed(seed + 5)
+    ro = rollout_from_policy(p, T, N, O, A, 1, seed + 6, kind)  # feat_len 0 breaks a2c/storage.py:171
+    with torch.no_grad():
+        nv = p.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    perturb(p, pert, seed + 7)  # move the policy off the behaviour policy so clipping is exercised
+    params0 = flat_params(p)
+    agent = ns.PPO(p, clip, E, M, 0.5, ecoef, lr=lr, eps=1e-5, max_grad_norm=0.5)
+    arrs = rollout_arrays(ro)
+    _REC.clear()
+    torch.manual_seed(seed + 8)
+    vl, al, de = agent.update(ro)
+    perms = np.stack([r for k, r in _REC if k == "randperm"]).astype(np.int64)
+    assert perms.shape == (E, T * N)
+    adv = ro.returns[:-1] - ro.value_preds[:-1]
+    adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+    st = agent.optimizer.state_dict()["state"]
+    exp_avg = np.concatenate([st[i]["exp_avg"].numpy().reshape(-1) for i in range(len(st))])
+    exp_avg_sq = np.concatenate([st[i]["exp_avg_sq"].numpy().reshape(-1) for i in range(len(st))])
+    # optimizer param order == module.parameters() order == state_dict order here
+    save(name, meta=meta(kind=kind, O=O, A=A, H=H, num_feet=f, T=T, N=N, ppo_epoch=E,
+                         num_mini_batch=M, clip_param=clip, entropy_coef=ecoef, lr=lr, eps=1e-5,
+                         value_loss_coef=0.5, max_grad_norm=0.5),
+         params0=params0, params1=flat_params(p), perms=perms, advantages=adv.numpy(),
+         losses=np.array([vl, al, de], np.float64), adam_m=exp_avg, adam_v=exp_avg_sq, **arrs)
+
+
+# ----------------------------------------------------------------------- D. D
+def gen_disc(name, F, Hd, B, Ne, T, N, epochs, seed):
+    from torch.utils.data import DataLoader, TensorDataset
+    torch.manual_seed(seed)
+    D = ns.Discriminator(F, Hd, "cpu")
+    params0 = flat_params(D.trunk)
+    g = torch.Generator().manual_seed(seed + 1)
+    expert = torch.randn(Ne, F, generator=g) * 0.8 + 0.3
+    ro = ns.RolloutStorage(T, N, (3,), ns.Box(shape=(2,)), 1, F)
+    fill_rollout(ro, T, N, 3, 2, F, seed + 2)
+    loader = DataLoader(TensorDataset(expert), batch_size=B, shuffle=True, drop_last=Ne > B)
+    out = {}
+    for ep in range(epochs):
+        _REC.clear()
+        torch.manual_seed(seed + 10 + ep)
+        loss = D.update_gail_dyn(loader, ro)
+        rps = [r for k, r in _REC if k == "randperm"]
+        alphas = [r for k, r in _REC if k == "rand"]
+        out[f"expert_perm{ep}"] = rps[0].astype(np.int64)   # DataLoader sampler draws first
+        out[f"policy_perm{ep}"] = rps[1].astype(np.int64)
+        assert len(rps[0]) == Ne and len(rps[1]) == T * N
+        out[f"alpha{ep}"] = np.concatenate([a.reshape(-1) for a in alphas]).astype(np.float32)
+        out[f"losses{ep}"] = np.array(loss, np.float64)
+        out[f"params_after{ep}"] = flat_params(D.trunk)
+        out[f"n_steps{ep}"] = np.int64(len(alphas))
+    save(name, meta=meta(F=F, Hd=Hd, B=B, Ne=Ne, T=T, N=N, epochs=epochs), params0=params0,
+         expert=expert.numpy(), obs_feat=ro.obs_feat.numpy().copy(), **out)
+
+
+# ----------------------------------------------------------------- E. relabel
+def gen_relabel(name, F, Hd, T, N, seed):
+    torch.manual_seed(seed)
+    D = ns.Discriminator(F, Hd, "cpu")
+    with torch.no_grad():
+        for q in D.trunk.parameters():
+            q.mul_(3.0)  # widen logits so sigmoid saturation / the 1e-7 terms matter
+    params = flat_params(D.trunk)
+    rms = ns.RunningMeanStd(shape=())
+    out = {}
+    for call in range(2):
+        ro = ns.RolloutStorage(T, N, (3,), ns.Box(shape=(2,)), 1, F)
+        fill_rollout(ro, T, N, 3, 2, F, seed + 3 + call)
+        ro.obs_feat.mul_(2.0)
+        offset = -0.37 if call == 0 else 0.21
+        rets = []
+        for step in range(T):  # a2c/main_gail_dyn_ppo.py:275-292
+            ro.rewards[step], returns = D.predict_reward_combined(ro.obs_feat[step + 1], 0.99, ro.masks[step], offset=offset)
+            if step == 0 and call == 0:
+                out["raw_reward0"] = ro.rewards[0].numpy().copy()
+            rms.update(returns.view(-1).cpu().numpy())
+            rews = ro.rewards[step].view(-1).cpu().numpy()
+            rews = np.clip(rews / np.sqrt(rms.var + 1e-7), -10.0, 10.0)
+            ro.rewards[step] = torch.Tensor(rews).view(-1, 1)
+            rets.append(returns.numpy().copy())
+        out[f"obs_feat{call}"] = ro.obs_feat.numpy().copy()
+        out[f"masks{call}"] = ro.masks.numpy().copy()
+        out[f"offset{call}"] = np.float64(offset)
+        out[f"rewards{call}"] = ro.rewards.numpy().copy()
+        out[f"d_returns{call}"] = D.returns.numpy().copy()
+        out[f"rms{call}"] = np.array([rms.mean, rms.var, rms.count], np.float64)
+    save(name, meta=meta(F=F, Hd=Hd, T=T, N=N, gamma=0.99), params=params, **out)
+
+
+def gen_rms():
+    rms = ns.RunningMeanStd(shape=())
+    g = np.random.RandomState(5)
+    xs, states = [], []
+    for i in range(5):
+        x = (g.randn(17) * (1 + i) + i).astype(np.float32)
+        rms.update(x)
+        xs.append(x)
+        states.append([rms.mean, rms.var, rms.count])
+    save("rms", xs=np.stack(xs), states=np.array(states, np.float64))
+
+
+# ----------------------------------------------------- F. full outer iteration
+def gen_iteration(name, kind, O, A, H, f, F, Hd, T, N, B, Ne, E, M, Ed, iters, seed):
+    """a2c/main_gail_dyn_ppo.py:239-304 on a synthetic rollout source, `iters` outer iterations."""
+    from torch.utils.data import DataLoader, TensorDataset
+    p = make_policy(kind, O, A, H, f, seed)
+    torch.manual_seed(seed + 1)
+    D = ns.Discriminator(F, Hd, "cpu")
+    agent = ns.PPO(p, 0.2, E, M, 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    g = torch.Generator().manual_seed(seed + 2)
+    expert = torch.randn(Ne, F, generator=g)
+    loader = DataLoader(TensorDataset(expert), batch_size=B, shuffle=True, drop_last=Ne > B)
+    gail_tar_length = 37.0
+    rms = ns.RunningMeanStd(shape=())
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, F)
+    ro.obs[0].copy_(torch.randn(N, O, generator=g))
+    out = dict(pi_params0=flat_params(p), d_params0=flat_params(D.trunk), expert=expert.numpy(),
+               obs0=ro.obs[0].numpy().copy())
+    for j in range(iters):
+        # synthetic rollout fill: act -> fake env -> insert   (:209-236)
+        noises, envs = [], []
+        for step in range(T):
+            with torch.no_grad():
+                torch.manual_seed(seed + 100 + 1000 * j + step)
+                noises.append(torch.randn(N, A).numpy())
+                torch.manual_seed(seed + 100 + 1000 * j + step)
+                value, action, logp, hxs = p.act(ro.obs[step], ro.recurrent_hidden_states[step], ro.masks[step])
+            obs = torch.randn(N, O, generator=g)
+            reward = torch.randn(N, 1, generator=g)
+            masks = (torch.rand(N, 1, generator=g) > 0.1).float()
+            bad = (torch.rand(N, 1, generator=g) > 0.05).float()
+            feat = torch.randn(N, F, generator=g)
+            envs.append((obs.numpy().copy(), reward.numpy().copy(), masks.numpy().copy(),
+                         bad.numpy().copy(), feat.numpy().copy()))
+            ro.insert(obs, hxs, action, logp, value, reward, masks, bad, feat)
+        out[f"it{j}_noise"] = np.stack(noises)
+        for i, nm in enumerate(("env_obs", "env_reward", "env_masks", "env_bad", "env_feat")):
+            out[f"it{j}_{nm}"] = np.stack([e[i] for e in envs])
+        out[f"it{j}_actions"] = ro.actions.numpy().copy()
+        out[f"it{j}_action_log_probs"] = ro.action_log_probs.numpy().copy()
+        out[f"it{j}_value_preds_rollout"] = ro.value_preds.numpy().copy()
+        with torch.no_grad():
+            nv = p.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()
+        out[f"it{j}_next_value"] = nv.numpy().copy()
+        dl = []
+        for ep in range(Ed):  # :255-256
+            _REC.clear()
+            torch.manual_seed(seed + 500 + 10 * j + ep)
+            dl.append(D.update_gail_dyn(loader, ro))
+            rps = [r for k, r in _REC if k == "randperm"]
+            out[f"it{j}_d{ep}_expert_perm"] = rps[0].astype(np.int64)
+            out[f"it{j}_d{ep}_policy_perm"] = rps[1].astype(np.int64)
+            out[f"it{j}_d{ep}_alpha"] = np.concatenate([r.reshape(-1) for k, r in _REC if k == "rand"]).astype(np.float32)
+        out[f"it{j}_d_losses"] = np.array(dl, np.float64)
+        out[f"it{j}_d_params"] = flat_params(D.trunk)
+        # alive bonus :258-271
+        num_of_dones = (1.0 - ro.masks).sum().cpu().numpy() + N / 2
+        num_of_expert_dones = (T * N) / gail_tar_length
+        d_sa = 1 - num_of_dones / (num_of_dones + num_of_expert_dones)
+        r_sa = np.log(d_sa) - np.log(1 - d_sa)
+        out[f"it{j}_r_sa"] = np.float64(r_sa)
+        for step in range(T):  # :275-292
+            ro.rewards[step], returns = D.predict_reward_combined(ro.obs_feat[step + 1], 0.99, ro.masks[step], offset=-r_sa)
+            rms.update(returns.view(-1).cpu().numpy())
+            rews = ro.rewards[step].view(-1).cpu().numpy()
+            rews = np.clip(rews / np.sqrt(rms.var + 1e-7), -10.0, 10.0)
+            ro.rewards[step] = torch.Tensor(rews).view(-1, 1)
+        out[f"it{j}_rewards"] = ro.rewards.numpy().copy()
+        out[f"it{j}_rms"] = np.array([rms.mean, rms.var, rms.count], np.float64)
+        out[f"it{j}_d_returns"] = D.returns.numpy().copy()
+        ro.compute_returns(nv, True, 0.99, 0.95, True)  # :299
+        out[f"it{j}_returns"] = ro.returns.numpy().copy()
+        _REC.clear()
+        torch.manual_seed(seed + 900 + j)
+        losses = agent.update(ro)  # :302
+        out[f"it{j}_ppo_perms"] = np.stack([r for k, r in _REC if k == "randperm"]).astype(np.int64)
+        out[f"it{j}_ppo_losses"] = np.array(losses, np.float64)
+        out[f"it{j}_pi_params"] = flat_params(p)
+        ro.after_update()  # :304
+    save(name, meta=meta(kind=kind, O=O, A=A, H=H, num_feet=f, F=F, Hd=Hd, T=T, N=N, B=B, Ne=Ne,
+                         ppo_epoch=E, num_mini_batch=M, gail_epoch=Ed, iters=iters,
+                         gail_tar_length=gail_tar_length, gamma=0.99, gae_lambda=0.95), **out)
+
+
+if __name__ == "__main__":
+    gen_policy("policy_mlp_tiny", "mlp", 5, 2, 8, 1, 16, 100)
+    gen_policy("policy_mlp_northstar", "mlp", 47, 12, 64, 1, 24, 110)
+    gen_policy("policy_mlp_hopper", "mlp", 11, 3, 64, 1, 8, 120)
+    gen_policy("policy_split_hopper", "split", 14, 7, 100, 1, 20, 130)
+    gen_policy("policy_split_laikago", "split", 64, 28, 100, 4, 12, 140)
+    gen_policy("policy_split_tiny", "split", 6, 7, 12, 1, 9, 150)
+    gen_gae()
+    gen_rms()
+    gen_ppo("ppo_mlp_tiny", "mlp", 5, 2, 8, 1, T=8, N=4, E=2, M=2, clip=0.2, ecoef=0.01, lr=3e-4, seed=200, pert=0.05)
+    gen_ppo("ppo_mlp_northstar", "mlp", 47, 12, 64, 1, T=16, N=8, E=3, M=4, clip=0.2, ecoef=0.0, lr=3e-4, seed=210)
+    gen_ppo("ppo_mlp_onestep", "mlp", 11, 3, 64, 1, T=10, N=6, E=1, M=1, clip=0.1, ecoef=0.01, lr=1.5e-4, seed=220, pert=0.05)
+    gen_ppo("ppo_split_hopper", "split", 14, 7, 100, 1, T=12, N=8, E=2, M=3, clip=0.2, ecoef=0.0, lr=3e-4, seed=230)
+    gen_ppo("ppo_split_laikago", "split", 64, 28, 100, 4, T=8, N=8, E=2, M=2, clip=0.2, ecoef=0.01, lr=3e-4, seed=240)
+    gen_disc("disc_tiny", F=7, Hd=16, B=8, Ne=40, T=4, N=8, epochs=2, seed=300)
+    gen_disc("disc_northstar", F=86, Hd=100, B=128, Ne=400, T=8, N=64, epochs=2, seed=310)
+    gen_disc("disc_hopper", F=25, Hd=100, B=128, Ne=300, T=16, N=16, epochs=1, seed=320)
+    gen_disc("disc_single_batch", F=7, Hd=16, B=8, Ne=8, T=4, N=8, epochs=1, seed=330)  # Ne == B: drop_last False, one batch (Ne < B raises in the reference)
+    gen_relabel("relabel_tiny", F=7, Hd=16, T=6, N=5, seed=400)
+    gen_relabel("relabel_northstar", F=86, Hd=100, T=8, N=32, seed=410)
+    gen_iteration("iter_mlp", "mlp", 47, 12, 64, 1, F=86, Hd=100, T=8, N=16, B=32, Ne=200, E=2, M=2, Ed=2, iters=2, seed=500)
+    gen_iteration("iter_split", "split", 14, 7, 100, 1, F=25, Hd=100, T=8, N=16, B=32, Ne=100, E=2, M=2, Ed=2, iters=2, seed=510)
