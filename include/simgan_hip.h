@@ -1,0 +1,197 @@
+/*
+ * simgan_hip.h -- C ABI of libsimgan_hip.so: SimGAN's GAIL+PPO update path as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (jyf588/SimGAN) has no FFI: its hot path sits behind Python
+ * classes.  Each entry point below replaces the body of
+ * one reference method; the Python shim in simgan_amd/ keeps the reference's
+ * class/method surface and binds these symbols with ctypes.
+ * a2c/ = third_party/a2c_ppo_acktr/ in the reference tree.
+ *
+ * Conventions
+ *   - plain C types only; all tensors are float32, row-major, caller-owned HOST
+ *     pointers unless a name says "dev"; indices are int64.
+ *   - every function returns 0 on success, <0 on error; sg_last_error() returns
+ *     a thread-local message.
+ *   - handles are opaque; one sg_ctx per GPU/process; not thread-safe (the
+ *     reference learner is single-threaded: a2c/main_gail_dyn_ppo.py:64).
+ *   - every stochastic input is optional by pointer: pass the reference's
+ *     RNG artefacts (permutations / alpha / noise) for parity, or NULL to use
+ *     the library's own counter-based generator seeded by `seed`.
+ *   - flat parameter vectors use torch state_dict order of the reference
+ *     modules (see oracle/sg_oracle.c header for the exact order).
+ */
+#ifndef SIMGAN_HIP_H
+#define SIMGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sg_ctx sg_ctx;
+typedef struct sg_policy sg_policy;
+typedef struct sg_rollout sg_rollout;
+typedef struct sg_ppo sg_ppo;
+typedef struct sg_disc sg_disc;
+
+/* ------------------------------------------------------------------ context */
+const char *sg_last_error(void);
+const char *sg_version(void);
+/* Creates the context on HIP device `device` (one stream, scratch arenas). */
+int sg_ctx_create(int device, sg_ctx **out);
+int sg_ctx_destroy(sg_ctx *ctx);
+int sg_ctx_synchronize(sg_ctx *ctx);
+/* Device properties the bench reports: name, CU count, HBM bytes. */
+int sg_ctx_device_info(sg_ctx *ctx, char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
+
+/* Data-parallel communicator over RCCL (one process per GPU, xGMI). Replaces nothing in the
+ * reference (single process, a2c/main_gail_dyn_ppo.py:64); added per BASELINE.json north_star.
+ * id is the 128-byte ncclUniqueId produced on rank 0 and broadcast by the host launcher. */
+int sg_comm_unique_id(uint8_t id[128]);
+int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
+int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
+
+/* ------------------------------------------------------------------- policy */
+enum { SG_POLICY_MLP = 0, SG_POLICY_SPLIT = 1 };
+/* Policy(obs_shape, action_space, base_kwargs)            a2c/model.py:38-67   (kind MLP)
+ * SplitPolicy(obs_shape, action_space, base_kwargs)       a2c/model_split.py:40-52 (kind SPLIT;
+ * requires act_dim == 7*num_feet, a2c/model_split.py:205). Parameters start at zero. */
+int sg_policy_create(sg_ctx *ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet,
+                     sg_policy **out);
+int sg_policy_destroy(sg_policy *p);
+int sg_policy_num_params(const sg_policy *p, int64_t *n);
+/* nn.Module.load_state_dict / state_dict, flattened. */
+int sg_policy_set_params(sg_policy *p, const float *flat, int64_t n);
+int sg_policy_get_params(sg_policy *p, float *flat, int64_t n);
+/* Policy.act a2c/model.py:89-101, SplitPolicy.act a2c/model_split.py:70-82.
+ * obs[n,O]; noise[n,A] standard normal draws or NULL (-> library RNG with `seed`);
+ * deterministic != 0 -> dist.mode().  Outputs value[n], action[n,A], logp[n]. */
+int sg_policy_act(sg_policy *p, const float *obs, int n, const float *noise, uint64_t seed,
+                  int deterministic, float *value, float *action, float *logp);
+/* Policy.get_value a2c/model.py:103-105 */
+int sg_policy_get_value(sg_policy *p, const float *obs, int n, float *value);
+/* Policy.evaluate_actions a2c/model.py:107-114: value[n], logp[n], *entropy = dist.entropy().mean() */
+int sg_policy_evaluate(sg_policy *p, const float *obs, const float *action, int n, float *value,
+                       float *logp, float *entropy);
+
+/* ------------------------------------------------------------------ rollout */
+/* RolloutStorage(num_steps, num_processes, obs_shape, action_space, rhs, feat_len) a2c/storage.py:32-56.
+ * Device-resident buffers, same shapes and row-major (t, n, ·) order as the reference. */
+enum {
+    SG_F_OBS = 0,          /* [T+1, N, O] */
+    SG_F_OBS_FEAT = 1,     /* [T+1, N, F] */
+    SG_F_ACTIONS = 2,      /* [T,   N, A] */
+    SG_F_REWARDS = 3,      /* [T,   N]    */
+    SG_F_VALUE_PREDS = 4,  /* [T+1, N]    */
+    SG_F_RETURNS = 5,      /* [T+1, N]    */
+    SG_F_LOGP = 6,         /* [T,   N]  action_log_probs */
+    SG_F_MASKS = 7,        /* [T+1, N]    */
+    SG_F_BAD_MASKS = 8,    /* [T+1, N]    */
+    SG_F_ADVANTAGES = 9,   /* [T,   N]  normalised advantages of the last sg_ppo_update (read-only) */
+    SG_F_COUNT = 10
+};
+int sg_rollout_create(sg_ctx *ctx, int T, int N, int obs_dim, int act_dim, int feat_dim,
+                      sg_rollout **out);
+int sg_rollout_destroy(sg_rollout *r);
+/* Whole-field host<->device copies; count = number of floats (must equal the field size). */
+int sg_rollout_upload(sg_rollout *r, int field, const float *host, int64_t count);
+int sg_rollout_download(sg_rollout *r, int field, float *host, int64_t count);
+/* One time-slot [t] of a field (N * width floats): the reference's rollouts.obs[step].copy_(..). */
+int sg_rollout_upload_step(sg_rollout *r, int field, int t, const float *host, int64_t count);
+int sg_rollout_download_step(sg_rollout *r, int field, int t, float *host, int64_t count);
+/* RolloutStorage.after_update a2c/storage.py:96-101: slot T -> slot 0 for obs, obs_feat, masks, bad_masks */
+int sg_rollout_after_update(sg_rollout *r);
+/* RolloutStorage.compute_returns a2c/storage.py:103-142 (all four branches); next_value[N] host. */
+int sg_rollout_compute_returns(sg_rollout *r, const float *next_value, int use_gae, float gamma,
+                               float gae_lambda, int use_proper_time_limits);
+/* Same, with next_value = policy.get_value(obs[T]) computed on device (a2c/main_gail_dyn_ppo.py:239-242,299). */
+int sg_rollout_compute_returns_policy(sg_rollout *r, sg_policy *p, int use_gae, float gamma,
+                                      float gae_lambda, int use_proper_time_limits);
+/* Synthetic rollout fill on device for benchmarks: obs, obs_feat ~ N(0,1);
+ * actions/logp/value_preds from policy.act; masks ~ Bernoulli(1-p_done); bad_masks = 1. */
+int sg_rollout_fill_synthetic(sg_rollout *r, sg_policy *p, uint64_t seed, float p_done);
+
+/* ---------------------------------------------------------------------- PPO */
+typedef struct {
+    float clip_param;
+    int ppo_epoch;
+    int num_mini_batch;
+    float value_loss_coef;
+    float entropy_coef;
+    float lr;
+    float eps;
+    float max_grad_norm;
+    int use_clipped_value_loss;
+} sg_ppo_config;
+/* PPO(actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef, lr, eps,
+ *     max_grad_norm, use_clipped_value_loss)  a2c/algo/ppo.py:30-63 (Adam state starts at zero). */
+int sg_ppo_create(sg_ctx *ctx, sg_policy *p, const sg_ppo_config *cfg, sg_ppo **out);
+int sg_ppo_destroy(sg_ppo *a);
+/* optimizer.param_groups[i]['lr'] = lr  (a2c/utils.py:68-72 update_linear_schedule) */
+int sg_ppo_set_lr(sg_ppo *a, float lr);
+/* PPO.update(rollouts) a2c/algo/ppo.py:65-157 -> out3 = {value_loss, action_loss, dist_entropy}.
+ * perms: [ppo_epoch][T*N] int64 = the permutation each epoch's sampler draws
+ * (a2c/storage.py:159-162), or NULL -> device-generated from `seed`. */
+int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, uint64_t seed, float out3[3]);
+/* Adam state access for checkpoint/parity: m, v flat [n] in state_dict order; *step = t. */
+int sg_ppo_get_adam(sg_ppo *a, float *m, float *v, int64_t n, int64_t *step);
+int sg_ppo_set_adam(sg_ppo *a, const float *m, const float *v, int64_t n, int64_t step);
+
+/* ------------------------------------------------------------ discriminator */
+/* Discriminator(input_dim, hidden_dim, device) a2c/algo/gail.py:35-51; Adam(lr 1e-3, eps 1e-8). */
+int sg_disc_create(sg_ctx *ctx, int input_dim, int hidden_dim, sg_disc **out);
+int sg_disc_destroy(sg_disc *d);
+int sg_disc_num_params(const sg_disc *d, int64_t *n);
+int sg_disc_set_params(sg_disc *d, const float *flat, int64_t n);
+int sg_disc_get_params(sg_disc *d, float *flat, int64_t n);
+int sg_disc_get_adam(sg_disc *d, float *m, float *v, int64_t n, int64_t *step);
+int sg_disc_set_adam(sg_disc *d, const float *m, const float *v, int64_t n, int64_t step);
+/* The expert matrix [n_rows, input_dim] (a2c/main_gail_dyn_ppo.py:163-165) stays resident in HBM. */
+int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
+/* Discriminator.update_gail_dyn(expert_loader, rollouts) a2c/algo/gail.py:154-193, one epoch.
+ * batch_size = expert_loader.batch_size; n_d = min(n_expert/batch, T*N/batch) steps.
+ * expert_perm[n_expert] (DataLoader shuffle), policy_perm[T*N] (feed_forward_generator),
+ * alpha[n_d*batch] (torch.rand per step, a2c/algo/gail.py:72) -- each may be NULL -> `seed`.
+ * out3 = {mean(gail_loss+grad_pen), mean expert_loss, mean policy_loss}; *n_steps = n_d.
+ * n_expert < batch_size is an error (the reference raises on the size mismatch). */
+int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm,
+                            const int64_t *policy_perm, const float *alpha, uint64_t seed,
+                            float out3[3], int *n_steps);
+/* Discriminator.predict_reward_combined(d_in, gamma, masks, offset) a2c/algo/gail.py:201-210.
+ * x[n,F], masks[n] -> reward[n], returns[n]; Discriminator.returns persists inside the handle
+ * (first call: returns = reward).  n must stay the same across calls. */
+int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma, const float *masks,
+                           float offset, float *reward, float *returns);
+int sg_disc_reset_returns(sg_disc *d);
+int sg_disc_get_returns(sg_disc *d, float *returns, int n, int *is_none);
+int sg_disc_set_returns(sg_disc *d, const float *returns, int n);
+/* Fused reward relabel, all T steps on device: a2c/main_gail_dyn_ppo.py:275-292
+ *   for t: rewards[t], ret = predict_reward_combined(obs_feat[t+1], gamma, masks[t], offset)
+ *          ret_rms.update(ret); rewards[t] = clip(rewards[t]/sqrt(ret_rms.var+1e-7), -10, 10)
+ * rms_state = {mean, var, count} float64 (RunningMeanStd, a2c/baselines/common/running_mean_std.py:27-58),
+ * updated in place.  Writes rollout field REWARDS. */
+int sg_disc_relabel_rewards(sg_disc *d, sg_rollout *r, float gamma, float offset,
+                            double rms_state[3]);
+/* sum(1 - masks) over all T+1 slots (a2c/main_gail_dyn_ppo.py:258), for the alive-bonus offset. */
+int sg_rollout_count_dones(sg_rollout *r, double *dones);
+
+/* ------------------------------------------------------------- measurement */
+/* HIP-event timing of the dominant kernels on the library's stream since the last reset:
+ * which = 0 discriminator gradient kernel, 1 discriminator reduce+Adam, 2 PPO gradient kernel,
+ * 3 PPO reduce, 4 PPO clip+Adam, 5 relabel forward.  Enabled by sg_ctx_profile(ctx, 1); adds
+ * event records around every launch (do not enable inside the timed bench region). */
+int sg_ctx_profile(sg_ctx *ctx, int enable);
+int sg_ctx_profile_read(sg_ctx *ctx, int which, double *total_ms, int64_t *launches);
+int sg_ctx_profile_reset(sg_ctx *ctx);
+
+/* Test hook: C[M,N] = op(A) op(B) through the LDS/MFMA tile engine (mode 0 NT, 1 NN, 2 TN),
+ * all dims multiples of 16, host pointers.  Used by tests/test_gemm_engine.py only. */
+int sg_test_gemm(sg_ctx *ctx, int mode, int M, int N, int K, const float *A, const float *B,
+                 float *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMGAN_HIP_H */

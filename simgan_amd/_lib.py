@@ -1,0 +1,198 @@
+"""ctypes binding of libsimgan_hip.so (the C ABI declared in include/simgan_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or fails to load, importing
+anything that needs it raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C simgan_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimgan_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_i64_p = C.POINTER(C.c_int64)
+c_double_p = C.POINTER(C.c_double)
+c_u8_p = C.POINTER(C.c_uint8)
+c_int_p = C.POINTER(C.c_int)
+H = C.c_void_p  # opaque handle
+
+# field ids (include/simgan_hip.h)
+F_OBS, F_OBS_FEAT, F_ACTIONS, F_REWARDS, F_VALUE_PREDS, F_RETURNS, F_LOGP, F_MASKS, F_BAD_MASKS, \
+    F_ADVANTAGES = range(10)
+POLICY_MLP, POLICY_SPLIT = 0, 1
+PROF_DISC_GRAD, PROF_DISC_ADAM, PROF_PPO_GRAD, PROF_PPO_REDUCE, PROF_PPO_ADAM, PROF_RELABEL = range(6)
+
+
+class PPOConfig(C.Structure):
+    _fields_ = [("clip_param", C.c_float), ("ppo_epoch", C.c_int), ("num_mini_batch", C.c_int),
+                ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float), ("lr", C.c_float),
+                ("eps", C.c_float), ("max_grad_norm", C.c_float),
+                ("use_clipped_value_loss", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol of include/simgan_hip.h
+PROTOTYPES = {
+    "sg_last_error": (C.c_char_p, []),
+    "sg_version": (C.c_char_p, []),
+    "sg_ctx_create": (C.c_int, [C.c_int, C.POINTER(H)]),
+    "sg_ctx_destroy": (C.c_int, [H]),
+    "sg_ctx_synchronize": (C.c_int, [H]),
+    "sg_ctx_device_info": (C.c_int, [H, C.c_char_p, C.c_int, c_int_p, c_i64_p]),
+    "sg_comm_unique_id": (C.c_int, [c_u8_p]),
+    "sg_ctx_comm_init": (C.c_int, [H, c_u8_p, C.c_int, C.c_int]),
+    "sg_ctx_comm_info": (C.c_int, [H, c_int_p, c_int_p]),
+    "sg_policy_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
+    "sg_policy_destroy": (C.c_int, [H]),
+    "sg_policy_num_params": (C.c_int, [H, c_i64_p]),
+    "sg_policy_set_params": (C.c_int, [H, c_float_p, C.c_int64]),
+    "sg_policy_get_params": (C.c_int, [H, c_float_p, C.c_int64]),
+    "sg_policy_act": (C.c_int, [H, c_float_p, C.c_int, c_float_p, C.c_uint64, C.c_int, c_float_p, c_float_p, c_float_p]),
+    "sg_policy_get_value": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
+    "sg_policy_evaluate": (C.c_int, [H, c_float_p, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p]),
+    "sg_rollout_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
+    "sg_rollout_destroy": (C.c_int, [H]),
+    "sg_rollout_upload": (C.c_int, [H, C.c_int, c_float_p, C.c_int64]),
+    "sg_rollout_download": (C.c_int, [H, C.c_int, c_float_p, C.c_int64]),
+    "sg_rollout_upload_step": (C.c_int, [H, C.c_int, C.c_int, c_float_p, C.c_int64]),
+    "sg_rollout_download_step": (C.c_int, [H, C.c_int, C.c_int, c_float_p, C.c_int64]),
+    "sg_rollout_after_update": (C.c_int, [H]),
+    "sg_rollout_compute_returns": (C.c_int, [H, c_float_p, C.c_int, C.c_float, C.c_float, C.c_int]),
+    "sg_rollout_compute_returns_policy": (C.c_int, [H, H, C.c_int, C.c_float, C.c_float, C.c_int]),
+    "sg_rollout_fill_synthetic": (C.c_int, [H, H, C.c_uint64, C.c_float]),
+    "sg_rollout_count_dones": (C.c_int, [H, c_double_p]),
+    "sg_ppo_create": (C.c_int, [H, H, C.POINTER(PPOConfig), C.POINTER(H)]),
+    "sg_ppo_destroy": (C.c_int, [H]),
+    "sg_ppo_set_lr": (C.c_int, [H, C.c_float]),
+    "sg_ppo_update": (C.c_int, [H, H, c_i64_p, C.c_uint64, c_float_p]),
+    "sg_ppo_get_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, c_i64_p]),
+    "sg_ppo_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
+    "sg_disc_create": (C.c_int, [H, C.c_int, C.c_int, C.POINTER(H)]),
+    "sg_disc_destroy": (C.c_int, [H]),
+    "sg_disc_num_params": (C.c_int, [H, c_i64_p]),
+    "sg_disc_set_params": (C.c_int, [H, c_float_p, C.c_int64]),
+    "sg_disc_get_params": (C.c_int, [H, c_float_p, C.c_int64]),
+    "sg_disc_get_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, c_i64_p]),
+    "sg_disc_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
+    "sg_disc_set_expert": (C.c_int, [H, c_float_p, C.c_int64]),
+    "sg_disc_update_gail_dyn": (C.c_int, [H, H, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
+    "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
+    "sg_disc_reset_returns": (C.c_int, [H]),
+    "sg_disc_get_returns": (C.c_int, [H, c_float_p, C.c_int, c_int_p]),
+    "sg_disc_set_returns": (C.c_int, [H, c_float_p, C.c_int]),
+    "sg_disc_relabel_rewards": (C.c_int, [H, H, C.c_float, C.c_float, c_double_p]),
+    "sg_ctx_profile": (C.c_int, [H, C.c_int]),
+    "sg_ctx_profile_read": (C.c_int, [H, C.c_int, c_double_p, c_i64_p]),
+    "sg_ctx_profile_reset": (C.c_int, [H]),
+    "sg_test_gemm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p]),
+}
+
+_LIB = None
+
+
+class SimganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsimgan_hip.so and bind every prototype.  Raises if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SimganHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
+            "run `make -C simgan_amd/csrc` (hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SimganHipError(load().sg_last_error().decode(errors="replace"))
+
+
+def fptr(a):
+    """float32 C-contiguous numpy array -> float* (no copy; caller keeps `a` alive)."""
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], (type(a), getattr(a, "dtype", None))
+    return a.ctypes.data_as(c_float_p)
+
+
+def i64ptr(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_i64_p)
+
+
+def as_f32(x):
+    """torch tensor / array-like -> contiguous float32 numpy (shares memory when possible)."""
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def as_i64(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+_CTX = {}
+
+
+class Context:
+    """One per process/GPU.  `default()` creates it on LOCAL_RANK (or device 0)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = H()
+        check(self.lib.sg_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self.rank, self.world = 0, 1
+
+    @staticmethod
+    def default():
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        if dev not in _CTX:
+            _CTX[dev] = Context(dev)
+        return _CTX[dev]
+
+    def synchronize(self):
+        check(self.lib.sg_ctx_synchronize(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_int64(0)
+        check(self.lib.sg_ctx_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(self.lib.sg_ctx_comm_init(self.h, buf, rank, world))
+        self.rank, self.world = rank, world
+
+    def profile(self, enable):
+        check(self.lib.sg_ctx_profile(self.h, 1 if enable else 0))
+
+    def profile_reset(self):
+        check(self.lib.sg_ctx_profile_reset(self.h))
+
+    def profile_read(self, which):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        check(self.lib.sg_ctx_profile_read(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    check(load().sg_comm_unique_id(buf))
+    return bytes(buf)

@@ -1,0 +1,191 @@
+"""Discriminator -- host mirror of a2c/algo/gail.py:34-217 (GAIL-dyn variant)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..utils import RunningMeanStd, to_host_tensor
+
+
+class _Trunk(object):
+    """`discr.trunk.state_dict()` view (trunk.0 / trunk.2 / trunk.4 Linear layers)."""
+
+    def __init__(self, d):
+        self._d = d
+
+    def state_dict(self):
+        d = self._d
+        flat, out, off = d.get_flat_params(), {}, 0
+        for name, shape in d.param_shapes():
+            n = int(np.prod(shape))
+            out[name] = to_host_tensor(flat[off:off + n].reshape(shape).copy())
+            off += n
+        return out
+
+    def load_state_dict(self, sd):
+        self._d.set_flat_params(np.concatenate([_lib.as_f32(sd[n]).reshape(-1) for n, _ in self._d.param_shapes()]))
+
+
+class Discriminator(object):
+    def __init__(self, input_dim, hidden_dim, device=None, ctx=None, seed=0):
+        self.device = device
+        self.input_dim, self.hidden_dim = int(input_dim), int(hidden_dim)
+        self.ctx = ctx or _lib.Context.default()
+        self.lib = self.ctx.lib
+        h = _lib.H()
+        _lib.check(self.lib.sg_disc_create(self.ctx.h, self.input_dim, self.hidden_dim, C.byref(h)))
+        self.h = h
+        n = C.c_int64(0)
+        _lib.check(self.lib.sg_disc_num_params(self.h, C.byref(n)))
+        self.num_params = n.value
+        self.trunk = _Trunk(self)
+        self.ret_rms = RunningMeanStd(shape=())  # unused field kept from a2c/algo/gail.py:51
+        self._expert_id = None
+        self._calls = 0
+        self.seed = 0xD15C
+        self._init_params(np.random.default_rng(seed))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.sg_disc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def param_shapes(self):
+        F, Hd = self.input_dim, self.hidden_dim
+        return [("0.weight", (Hd, F)), ("0.bias", (Hd,)), ("2.weight", (Hd, Hd)), ("2.bias", (Hd,)),
+                ("4.weight", (1, Hd)), ("4.bias", (1,))]
+
+    def _init_params(self, rng):
+        """nn.Linear default init (kaiming_uniform a=sqrt5 => U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        for weight and bias), a2c/algo/gail.py:40-43."""
+        parts = []
+        for name, shape in self.param_shapes():
+            fan_in = shape[1] if len(shape) == 2 else {"0.bias": self.input_dim}.get(name, self.hidden_dim)
+            b = 1.0 / np.sqrt(fan_in)
+            parts.append(rng.uniform(-b, b, size=int(np.prod(shape))).astype(np.float32))
+        self.set_flat_params(np.concatenate(parts))
+
+    def get_flat_params(self):
+        out = np.empty(self.num_params, np.float32)
+        _lib.check(self.lib.sg_disc_get_params(self.h, _lib.fptr(out), out.size))
+        return out
+
+    def set_flat_params(self, flat):
+        flat = _lib.as_f32(flat).reshape(-1)
+        _lib.check(self.lib.sg_disc_set_params(self.h, _lib.fptr(flat), flat.size))
+
+    def get_adam(self):
+        n = self.num_params
+        m, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        step = C.c_int64(0)
+        _lib.check(self.lib.sg_disc_get_adam(self.h, _lib.fptr(m), _lib.fptr(v), n, C.byref(step)))
+        return m, v, step.value
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    # ------------------------------------------------------------------ expert data
+    def set_expert(self, expert):
+        """Make the expert matrix [N_e, F] (a2c/main_gail_dyn_ppo.py:163-165) resident in HBM."""
+        e = _lib.as_f32(expert).reshape(-1, self.input_dim)
+        _lib.check(self.lib.sg_disc_set_expert(self.h, _lib.fptr(e), e.shape[0]))
+        self.n_expert = e.shape[0]
+
+    def _bind_loader(self, expert_loader):
+        """The reference passes a torch DataLoader over TensorDataset(expert); only its
+        .batch_size and the underlying matrix are needed (a2c/algo/gail.py:157-165)."""
+        ds = getattr(expert_loader, "dataset", None)
+        key = id(ds) if ds is not None else id(expert_loader)
+        if key != self._expert_id:
+            if ds is not None and hasattr(ds, "tensors"):
+                mat = ds.tensors[0]
+            elif ds is not None:
+                mat = np.stack([_lib.as_f32(ds[i][0]) for i in range(len(ds))])
+            else:
+                mat = expert_loader.expert
+            self.set_expert(mat)
+            self._expert_id = key
+        return int(expert_loader.batch_size)
+
+    # ---------------------------------------------------------------------- updates
+    def update_gail_dyn(self, expert_loader, rollouts, expert_perm=None, policy_perm=None, alpha=None):
+        """a2c/algo/gail.py:154-193, one epoch -> (loss, expert_loss, policy_loss) means.
+        expert_perm / policy_perm / alpha inject the reference's RNG artefacts (parity tests)."""
+        B = self._bind_loader(expert_loader)
+        rollouts._push([_lib.F_OBS_FEAT])
+        out = (C.c_float * 3)()
+        nst = C.c_int(0)
+        ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
+        pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
+        al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
+        self._calls += 1
+        _lib.check(self.lib.sg_disc_update_gail_dyn(
+            self.h, rollouts.h, B, None if ep is None else _lib.i64ptr(ep), None if pp is None else _lib.i64ptr(pp),
+            None if al is None else _lib.fptr(al), self.seed + self._calls, out, C.byref(nst)))
+        self.last_n_steps = nst.value
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def update(self, expert_loader, rollouts, obsfilt=None, is_gail_dyn=False, a_dim=None):
+        """a2c/algo/gail.py:91-152 (state/action GAIL): not called by any shipped driver
+        (a2c/main_gail_dyn_ppo.py:256 uses update_gail_dyn)."""
+        raise NotImplementedError("only the GAIL-dyn update (update_gail_dyn) is on the hot path")
+
+    # ---------------------------------------------------------------------- rewards
+    def predict_reward_combined(self, d_in, gamma, masks, offset=0.0):
+        """a2c/algo/gail.py:201-210 -> (reward [n,1], returns [n,1]); self.returns persists."""
+        x = _lib.as_f32(d_in).reshape(-1, self.input_dim)
+        n = x.shape[0]
+        m = _lib.as_f32(masks).reshape(-1)
+        reward = np.empty((n, 1), np.float32)
+        returns = np.empty((n, 1), np.float32)
+        _lib.check(self.lib.sg_disc_predict_reward(self.h, _lib.fptr(x), n, float(gamma), _lib.fptr(m),
+                                                   float(offset), _lib.fptr(reward), _lib.fptr(returns)))
+        self._last_n = n
+        return to_host_tensor(reward), to_host_tensor(returns)
+
+    def predict_reward(self, state, action, gamma, masks, offset=0.0):
+        """a2c/algo/gail.py:195-199"""
+        d_in = np.concatenate([_lib.as_f32(state), _lib.as_f32(action)], axis=1)
+        return self.predict_reward_combined(d_in, gamma, masks, offset)
+
+    @property
+    def returns(self):
+        none = C.c_int(0)
+        _lib.check(self.lib.sg_disc_get_returns(self.h, None, 0, C.byref(none)))
+        if none.value:
+            return None
+        n = self._returns_n()
+        out = np.empty((n, 1), np.float32)
+        _lib.check(self.lib.sg_disc_get_returns(self.h, _lib.fptr(out), n, C.byref(none)))
+        return to_host_tensor(out)
+
+    @returns.setter
+    def returns(self, value):
+        if value is None:
+            _lib.check(self.lib.sg_disc_reset_returns(self.h))
+        else:
+            v = _lib.as_f32(value).reshape(-1)
+            _lib.check(self.lib.sg_disc_set_returns(self.h, _lib.fptr(v), v.size))
+            self._ret_n = v.size
+
+    def _returns_n(self):
+        return getattr(self, "_ret_n", None) or self._last_n
+
+    def relabel_rewards(self, rollouts, gamma, offset, ret_rms):
+        """Fused a2c/main_gail_dyn_ppo.py:275-292 over all T steps on device; ret_rms is the caller's
+        RunningMeanStd (float64 state updated in place); rollouts.rewards is rewritten."""
+        rollouts._push([_lib.F_OBS_FEAT, _lib.F_MASKS])
+        st = (C.c_double * 3)(*ret_rms.get_state())
+        _lib.check(self.lib.sg_disc_relabel_rewards(self.h, rollouts.h, float(gamma), float(offset), st))
+        ret_rms.set_state([st[0], st[1], st[2]])
+        self._last_n = rollouts.num_processes
+        rollouts._pull([_lib.F_REWARDS])

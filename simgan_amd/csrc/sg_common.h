@@ -1,0 +1,174 @@
+// sg_common.h -- host-side structures shared by the translation units of libsimgan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/simgan_hip.h"
+#include "sg_gemm.hpp"
+
+void sg_set_error(const char* fmt, ...);
+
+#define SG_CHECK(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            sg_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,                \
+                         hipGetErrorString(_e));                                            \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+#define SG_REQUIRE(cond, ...)        \
+    do {                             \
+        if (!(cond)) {               \
+            sg_set_error(__VA_ARGS__); \
+            return -2;               \
+        }                            \
+    } while (0)
+
+#define SG_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != 0) return _r; \
+    } while (0)
+
+// ----------------------------------------------------------------------------- padded layouts
+// Device parameter vectors are stored "tile padded": a weight [n_out, n_in] occupies
+// [pad16(n_out)][pad16(n_in)+4] floats (zero in the padding) so that a trunk's parameter block is
+// byte-for-byte the LDS image the kernels compute on.  Adam moments and gradient slabs use the
+// same layout; padding entries have zero gradient forever and therefore stay zero.
+
+struct SgTrunk {       // one 2-hidden-layer tanh trunk + its stacked linear heads
+    int off;           // start of the block in the padded vector (floats)
+    int w1, b1, w2, b2, wh, bh, ex;  // offsets relative to `off`
+    int size;          // block length (floats, multiple of 4)
+    int P, Pp, ldP;    // head outputs (real / padded / LDS stride of the [R][Pp] output tile)
+    int EX;            // extra per-trunk vector (MLP actor: logstd[A]); 0 if none
+};
+
+struct SgPolicyDesc {
+    int kind, O, A, H, num_feet;
+    int Op, ldO, Hp, ldH;
+    int n_trunks;         // 2 (MLP: actor, critic) or 3 (split: contact, actuator, critic)
+    SgTrunk trunk[3];
+    int total;            // padded parameter count
+    int nc, na;           // split: 4*feet, 3*feet
+};
+
+struct SgDiscDesc {
+    int F, Hd, Fp, ldF, Hp, ldH;
+    int w1, b1, w2, b2, w3, b3;  // offsets in the padded vector
+    int total;
+};
+
+SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet);
+int64_t sg_policy_flat_count(const SgPolicyDesc& d);
+void sg_policy_pad(const SgPolicyDesc& d, const float* flat, float* padded);    // padded must be zeroed
+void sg_policy_unpad(const SgPolicyDesc& d, const float* padded, float* flat);
+SgDiscDesc sg_make_disc_desc(int F, int Hd);
+int64_t sg_disc_flat_count(const SgDiscDesc& d);
+void sg_disc_pad(const SgDiscDesc& d, const float* flat, float* padded);
+void sg_disc_unpad(const SgDiscDesc& d, const float* padded, float* flat);
+
+// ------------------------------------------------------------------------------------ handles
+enum { SG_PROF_DISC_GRAD = 0, SG_PROF_DISC_ADAM, SG_PROF_PPO_GRAD, SG_PROF_PPO_REDUCE,
+       SG_PROF_PPO_ADAM, SG_PROF_RELABEL, SG_PROF_COUNT };
+
+struct SgProfSlot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct SgComm;  // RCCL communicator (sg_comm.cpp)
+
+struct sg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 0;
+    int lds_bytes = 0;
+    bool profile = false;
+    SgProfSlot prof[SG_PROF_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    SgComm* comm = nullptr;
+    int rank = 0, world = 1;
+    // scratch
+    float* d_scratch = nullptr;   // generic device scratch (host<->device staging for API calls)
+    size_t scratch_bytes = 0;
+    void* h_pinned = nullptr;     // pinned host staging
+    size_t pinned_bytes = 0;
+};
+
+int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out);
+int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out);
+// profiling helpers: bracket a launch with events when ctx->profile is on
+void sg_prof_begin(sg_ctx* ctx, int which);
+void sg_prof_end(sg_ctx* ctx, int which);
+
+struct sg_policy {
+    sg_ctx* ctx;
+    SgPolicyDesc desc;
+    float* d_params = nullptr;   // padded
+    float* d_io = nullptr;       // staging for the host-pointer entry points
+    size_t io_bytes = 0;
+};
+
+struct sg_rollout {
+    sg_ctx* ctx;
+    int T, N, O, A, F;
+    float* d_field[SG_F_COUNT] = {nullptr};
+    int64_t field_count[SG_F_COUNT] = {0};
+    int field_slots[SG_F_COUNT] = {0};   // T or T+1
+    int field_width[SG_F_COUNT] = {0};
+    int64_t* d_perm = nullptr;           // [T*N] scratch permutation
+};
+
+struct sg_ppo {
+    sg_ctx* ctx;
+    sg_policy* policy;
+    sg_ppo_config cfg;
+    float *d_m = nullptr, *d_v = nullptr, *d_grad = nullptr;
+    float* d_slabs = nullptr;      // [n_slabs][total] per-workgroup partial gradients
+    int n_slabs = 0;
+    float* d_state = nullptr;      // device scalars: see SgOptState
+    int64_t* d_perms = nullptr;    // [ppo_epoch][T*N]
+    int64_t perms_cap = 0;
+    double* d_loss_acc = nullptr;  // [3] running loss sums over the update
+    float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
+};
+
+struct sg_disc {
+    sg_ctx* ctx;
+    SgDiscDesc desc;
+    float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr;
+    float* d_slabs = nullptr;
+    int n_slabs = 0;
+    float* d_state = nullptr;
+    float* d_expert = nullptr;
+    int64_t n_expert = 0;
+    int64_t *d_eperm = nullptr, *d_pperm = nullptr;
+    int64_t eperm_cap = 0, pperm_cap = 0;
+    float* d_alpha = nullptr;
+    int64_t alpha_cap = 0;
+    double* d_loss_acc = nullptr;
+    float* d_returns = nullptr;    // Discriminator.returns [n]
+    int returns_n = 0;
+    bool returns_none = true;
+    uint64_t rng_calls = 0;
+};
+
+// Device-side optimizer scalars (float): kept in device memory so captured/queued launches never
+// depend on host-side kernel arguments that change between steps.
+struct SgOptState {
+    float lr;
+    float step;      // Adam t (exact in fp32 up to 2^24 steps)
+    float pad[6];
+};
+
+// RCCL (sg_comm.cpp)
+int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n);
+int sg_comm_allreduce_f64(sg_ctx* ctx, double* dev, int64_t n);
+int sg_comm_allgather_f32(sg_ctx* ctx, const float* dev_in, float* dev_out, int64_t n_per_rank);

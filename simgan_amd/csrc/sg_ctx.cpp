@@ -1,0 +1,154 @@
+// sg_ctx.cpp -- context, error reporting, scratch arenas, HIP-event profiling slots.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "sg_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void sg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* sg_last_error(void) { return g_err; }
+extern "C" const char* sg_version(void) { return "simgan_hip 0.1 (gfx950)"; }
+
+extern "C" int sg_ctx_create(int device, sg_ctx** out) {
+    SG_REQUIRE(out != nullptr, "sg_ctx_create: out is NULL");
+    int count = 0;
+    SG_CHECK(hipGetDeviceCount(&count));
+    SG_REQUIRE(device >= 0 && device < count, "sg_ctx_create: device %d out of range (%d visible)", device, count);
+    SG_CHECK(hipSetDevice(device));
+    sg_ctx* ctx = new sg_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    SG_CHECK(hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->lds_bytes = (int)prop.sharedMemPerBlock;
+    SG_REQUIRE(strstr(prop.gcnArchName, "gfx950") != nullptr,
+               "sg_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    SG_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->prof)
+        for (auto& p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int sg_ctx_synchronize(sg_ctx* ctx) {
+    SG_REQUIRE(ctx, "sg_ctx_synchronize: ctx is NULL");
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_ctx_device_info(sg_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes) {
+    SG_REQUIRE(ctx, "sg_ctx_device_info: ctx is NULL");
+    hipDeviceProp_t prop;
+    SG_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (num_cu) *num_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out) {
+    if (bytes > ctx->scratch_bytes) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) SG_CHECK(hipFree(ctx->d_scratch));
+        size_t cap = bytes + bytes / 2 + 4096;
+        SG_CHECK(hipMalloc((void**)&ctx->d_scratch, cap));
+        ctx->scratch_bytes = cap;
+    }
+    *out = ctx->d_scratch;
+    return 0;
+}
+
+int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->pinned_bytes) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pinned) SG_CHECK(hipHostFree(ctx->h_pinned));
+        size_t cap = bytes + bytes / 2 + 4096;
+        SG_CHECK(hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault));
+        ctx->pinned_bytes = cap;
+    }
+    *out = ctx->h_pinned;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- profiling
+static hipEvent_t take_event(sg_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void sg_prof_begin(sg_ctx* ctx, int which) {
+    if (!ctx->profile) return;
+    hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
+    (void)hipEventRecord(e0, ctx->stream);
+    ctx->prof[which].pending.emplace_back(e0, e1);
+}
+
+void sg_prof_end(sg_ctx* ctx, int which) {
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->prof[which].pending.back().second, ctx->stream);
+}
+
+static void prof_drain(sg_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->prof) {
+        for (auto& p : s.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        s.pending.clear();
+    }
+}
+
+extern "C" int sg_ctx_profile(sg_ctx* ctx, int enable) {
+    SG_REQUIRE(ctx, "sg_ctx_profile: ctx is NULL");
+    prof_drain(ctx);
+    ctx->profile = enable != 0;
+    return 0;
+}
+
+extern "C" int sg_ctx_profile_read(sg_ctx* ctx, int which, double* total_ms, int64_t* launches) {
+    SG_REQUIRE(ctx, "sg_ctx_profile_read: ctx is NULL");
+    SG_REQUIRE(which >= 0 && which < SG_PROF_COUNT, "sg_ctx_profile_read: bad slot %d", which);
+    prof_drain(ctx);
+    if (total_ms) *total_ms = ctx->prof[which].total_ms;
+    if (launches) *launches = ctx->prof[which].launches;
+    return 0;
+}
+
+extern "C" int sg_ctx_profile_reset(sg_ctx* ctx) {
+    SG_REQUIRE(ctx, "sg_ctx_profile_reset: ctx is NULL");
+    prof_drain(ctx);
+    for (auto& s : ctx->prof) { s.total_ms = 0.0; s.launches = 0; }
+    return 0;
+}

@@ -1,0 +1,713 @@
+// sg_disc.hip -- GAIL discriminator: BCE-with-logits + gradient-penalty step (with the
+// hand-derived double backward), Adam, reward prediction and the fused reward relabel.
+//
+// Replaces (reference, a2c/ = third_party/a2c_ppo_acktr/):
+//   Discriminator.__init__                    a2c/algo/gail.py:35-51
+//   Discriminator.compute_grad_pen_combined   a2c/algo/gail.py:67-89
+//   Discriminator.update_gail_dyn             a2c/algo/gail.py:154-193
+//   Discriminator.predict_reward_combined     a2c/algo/gail.py:201-210
+//   reward relabel + RunningMeanStd           a2c/main_gail_dyn_ppo.py:275-292,
+//                                             a2c/baselines/common/running_mean_std.py:27-58
+//
+// One optimizer step = two launches queued back to back (n_d * gail_epoch of them per update):
+//   k_disc_grad   2*G workgroups, G = ceil(batch/16).  Workgroups [0,G) take 16 expert + 16 policy
+//                 rows through forward/BCE/backward; workgroups [G,2G) take the 16 matching mixup
+//                 rows through forward, input-gradient, penalty and the double backward.  The whole
+//                 parameter vector (its HBM image is the LDS image) is staged once per workgroup;
+//                 every contraction is an LDS-tile fp32 MFMA GEMM; partial gradients go to a
+//                 per-workgroup slab.
+//   k_disc_adam   sums the slabs per parameter and applies Adam (no clipping for D).
+//
+// Gradient-penalty math (x = mixup row, s_i = 1 - h_i^2, lambda = 10, B = batch):
+//   d2 = w3*s2; u1 = W2^T d2; d1 = u1*s1; g = W1^T d1; n = |g|; gb = lambda*(2/B)*(n-1)/n * g
+//   dW1 += d1 gb^T; bd1 = W1 gb; bu1 = bd1*s1; sb1 = bd1*u1; dW2 += d2 bu1^T; bd2 = W2 bu1
+//   dw3 += bd2*s2; sb2 = bd2*w3; z2b = (-2 h2 sb2)*s2; dW2 += z2b h1^T; db2 += z2b
+//   h1b = W2^T z2b - 2 h1 sb1; z1b = h1b*s1; dW1 += z1b x^T; db1 += z1b
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sg_common.h"
+#include "sg_rng.hpp"
+
+int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_t stream_id);
+
+struct DiscArgs {
+    SgDiscDesc d;
+    const float* params;
+    const float* expert;     // [n_expert, F]
+    const float* next_feat;  // obs_feat[1:] flattened [T*N, F]
+    const int64_t* eperm;    // this step's expert row ids  [B]
+    const int64_t* pperm;    // this step's policy row ids  [B]
+    const float* alpha;      // [B]
+    int B;                   // local rows of this step
+    int G;                   // ceil(B/16)
+    float inv_B;             // 1 / global batch rows
+    float lambda_;
+    float* slabs;
+    int slab_stride;
+    SgOptState* st;
+};
+
+__device__ __forceinline__ float sg_log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+static size_t disc_grad_lds_bytes(const SgDiscDesc& d) {
+    const size_t bce = (size_t)32 * d.ldF + 2 * 32 * d.ldH + 64;
+    const size_t mix = (size_t)2 * 16 * d.ldF + 6 * 16 * d.ldH + 64;
+    return sizeof(float) * ((size_t)d.total + (bce > mix ? bce : mix));
+}
+
+__global__ __launch_bounds__(256) void k_disc_grad(DiscArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SgDiscDesc& d = a.d;
+    const int tid = threadIdx.x;
+    const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp, F = d.F;
+    float* W = smem;
+    const float* W1 = W + d.w1;
+    const float* b1 = W + d.b1;
+    const float* W2 = W + d.w2;
+    const float* b2 = W + d.b2;
+    const float* w3 = W + d.w3;
+    float* buf = W + d.total;
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    if (blockIdx.x == 0 && tid == 0) a.st->step += 1.0f;  // Adam t for the k_disc_adam that follows
+
+    sg_stage(W, a.params, d.total / 4);
+
+    if ((int)blockIdx.x < a.G) {
+        // ------------------------------------------------ BCE group: rows 0-15 expert, 16-31 policy
+        constexpr int R = 32;
+        const int g = blockIdx.x;
+        float* X = buf;
+        float* H1 = X + R * ldF;
+        float* H2 = H1 + R * ldH;
+        float* DD = H2 + R * ldH;
+        float* LOSS = DD + R;
+        for (int i = tid; i < R * Fp; i += blockDim.x) {
+            const int r = i / Fp, c = i - r * Fp;
+            const int b = g * 16 + (r & 15);
+            float v = 0.f;
+            if (b < a.B && c < F)
+                v = (r < 16) ? a.expert[(size_t)a.eperm[b] * F + c] : a.next_feat[(size_t)a.pperm[b] * F + c];
+            X[r * ldF + c] = v;
+        }
+        __syncthreads();
+        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
+        __syncthreads();
+        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = tanhf(v + b2[c]); });
+        __syncthreads();
+        {   // logits, BCE losses and dL/dd: 8 lanes per row   (a2c/algo/gail.py:168-176)
+            const int r = tid >> 3, sub = tid & 7;
+            float s = 0.f;
+            for (int c = sub; c < Hp; c += 8) s += H2[r * ldH + c] * w3[c];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (sub == 0) {
+                const float dd = s + W[d.b3];
+                const bool valid = g * 16 + (r & 15) < a.B;
+                float loss = 0.f, grad = 0.f;
+                if (valid) {
+                    if (r < 16) { loss = -sg_log_sigmoid(dd); grad = a.inv_B * (sg_sigmoid(dd) - 1.f); }
+                    else { loss = dd - sg_log_sigmoid(dd); grad = a.inv_B * sg_sigmoid(dd); }
+                }
+                DD[r] = grad;
+                LOSS[r] = loss;
+            }
+        }
+        __syncthreads();
+        // dw3, db3 and dZ2 (in place over H2), one thread per hidden column
+        for (int c = tid; c < Hp; c += blockDim.x) {
+            const float w = w3[c];
+            float gw = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float h = H2[r * ldH + c], dd = DD[r];
+                gw += dd * h;
+                H2[r * ldH + c] = dd * w * (1.f - h * h);
+            }
+            slab[d.w3 + c] = gw;
+        }
+        if (tid < 16) {
+            float gb = 0.f;
+            if (tid == 0) for (int r = 0; r < R; ++r) gb += DD[r];
+            slab[d.b3 + tid] = gb;
+        }
+        if (tid == 64) {
+            float le = 0.f, lp = 0.f;
+            for (int r = 0; r < 16; ++r) { le += LOSS[r]; lp += LOSS[16 + r]; }
+            float* ls = slab + d.total;
+            ls[0] = le; ls[1] = lp; ls[2] = 0.f;
+        }
+        __syncthreads();
+        sg_grad_tn(H2, ldH, H1, ldH, R, Hp, Hp, slab + d.w2, ldH, false);
+        sg_colsum(H2, ldH, R, Hp, slab + d.b2, false);
+        __syncthreads();
+        sg_layer_nn<2>(H2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+            const float h = H1[r * ldH + c];
+            H1[r * ldH + c] = v * (1.f - h * h);
+        });
+        __syncthreads();
+        sg_grad_tn(H1, ldH, X, ldF, R, Hp, Fp, slab + d.w1, ldF, false);
+        sg_colsum(H1, ldH, R, Hp, slab + d.b1, false);
+    } else {
+        // ------------------------------------------------ mixup group: gradient penalty on 16 rows
+        constexpr int R = 16;
+        const int g = blockIdx.x - a.G;
+        float* XM = buf;
+        float* GX = XM + R * ldF;
+        float* H1 = GX + R * ldF;
+        float* H2 = H1 + R * ldH;
+        float* D2 = H2 + R * ldH;   // d2, later z2b
+        float* U1 = D2 + R * ldH;   // u1, later sb1
+        float* D1 = U1 + R * ldH;   // d1, later bd2*s2
+        float* BU1 = D1 + R * ldH;  // bu1, later z1b
+        float* ROWL = BU1 + R * ldH;
+        for (int i = tid; i < R * Fp; i += blockDim.x) {
+            const int r = i / Fp, c = i - r * Fp;
+            const int b = g * 16 + r;
+            float v = 0.f;
+            if (b < a.B && c < F) {
+                const float al = a.alpha[b];
+                v = al * a.expert[(size_t)a.eperm[b] * F + c] + (1.f - al) * a.next_feat[(size_t)a.pperm[b] * F + c];
+            }
+            XM[r * ldF + c] = v;
+        }
+        __syncthreads();
+        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
+        __syncthreads();
+        sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+            const float h = tanhf(v + b2[c]);
+            H2[r * ldH + c] = h;
+            D2[r * ldH + c] = w3[c] * (1.f - h * h);
+        });
+        __syncthreads();
+        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+            const float h = H1[r * ldH + c];
+            U1[r * ldH + c] = v;
+            D1[r * ldH + c] = v * (1.f - h * h);
+        });
+        __syncthreads();
+        sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });
+        __syncthreads();
+        {   // per-row |g|, penalty and gb = c_r * g: 16 lanes per row   (a2c/algo/gail.py:88)
+            const int r = tid >> 4, sub = tid & 15;
+            float s = 0.f;
+            for (int c = sub; c < Fp; c += 16) { const float v = GX[r * ldF + c]; s += v * v; }
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            const float nn = sqrtf(s);
+            const bool valid = g * 16 + r < a.B;
+            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
+            for (int c = sub; c < Fp; c += 16) GX[r * ldF + c] *= cr;
+            if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
+        }
+        __syncthreads();
+        sg_grad_tn(D1, ldH, GX, ldF, R, Hp, Fp, slab + d.w1, ldF, false);        // dW1  = d1^T gb
+        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {     // bd1 = gb W1^T
+            const float h = H1[r * ldH + c];
+            BU1[r * ldH + c] = v * (1.f - h * h);
+            U1[r * ldH + c] = v * U1[r * ldH + c];                                 // sb1 = bd1*u1
+        });
+        __syncthreads();
+        sg_grad_tn(D2, ldH, BU1, ldH, R, Hp, Hp, slab + d.w2, ldH, false);       // dW2  = d2^T bu1
+        __syncthreads();
+        sg_layer_nt<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {    // bd2 = bu1 W2^T
+            const float h = H2[r * ldH + c], s2 = 1.f - h * h;
+            D1[r * ldH + c] = v * s2;                                              // -> dw3
+            const float sb2 = v * w3[c];
+            D2[r * ldH + c] = (-2.f * h * sb2) * s2;                               // z2b
+        });
+        __syncthreads();
+        sg_colsum(D1, ldH, R, Hp, slab + d.w3, false);
+        sg_grad_tn(D2, ldH, H1, ldH, R, Hp, Hp, slab + d.w2, ldH, true);         // dW2 += z2b^T h1
+        sg_colsum(D2, ldH, R, Hp, slab + d.b2, false);
+        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {     // h1b = z2b W2
+            const float h = H1[r * ldH + c];
+            BU1[r * ldH + c] = (v - 2.f * h * U1[r * ldH + c]) * (1.f - h * h);    // z1b
+        });
+        __syncthreads();
+        sg_grad_tn(BU1, ldH, XM, ldF, R, Hp, Fp, slab + d.w1, ldF, true);        // dW1 += z1b^T x
+        sg_colsum(BU1, ldH, R, Hp, slab + d.b1, false);
+        if (tid < 16) slab[d.b3 + tid] = 0.f;
+        if (tid == 64) {
+            float lg = 0.f;
+            for (int r = 0; r < R; ++r) lg += ROWL[r];
+            float* ls = slab + d.total;
+            ls[0] = 0.f; ls[1] = 0.f; ls[2] = lg;
+        }
+    }
+}
+
+// out[i] = sum over slabs (data-parallel mode: feeds the all-reduce)
+__global__ void k_slab_sum(const float* slabs, int n_slabs, int slab_stride, int count, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float g = 0.f;
+    for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * slab_stride + i];
+    out[i] = g;
+}
+
+// Slab reduction + Adam (torch.optim.Adam defaults: lr 1e-3, betas (0.9, 0.999), eps 1e-8;
+// a2c/algo/gail.py:48,186-188) + running loss sums (a2c/algo/gail.py:181-184).
+__global__ __launch_bounds__(256) void k_disc_adam(float* params, float* m, float* v, const float* slabs,
+                                                   int n_slabs, int slab_stride, int total, const SgOptState* st,
+                                                   float eps, float inv_B, float lambda_, double* loss_acc) {
+    __shared__ float s_step_size, s_bc2_sqrt;
+    if (threadIdx.x == 0) {
+        const double t = (double)st->step;
+        const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+        s_step_size = (float)((double)st->lr / bc1);
+        s_bc2_sqrt = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        float g = 0.f;
+        for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * slab_stride + i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (g - mi) * (float)(1.0 - 0.9);
+        vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
+        const float denom = sqrtf(vi) / s_bc2_sqrt + eps;
+        params[i] = params[i] - s_step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < n_slabs; ++s) {
+            const float* ls = slabs + (size_t)s * slab_stride + total;
+            s0 += ls[0]; s1 += ls[1]; s2 += ls[2];
+        }
+        const float el = s0 * inv_B, pl = s1 * inv_B, gp = lambda_ * (s2 * inv_B);
+        loss_acc[0] += (double)(el + pl + gp);
+        loss_acc[1] += (double)el;
+        loss_acc[2] += (double)pl;
+    }
+}
+
+__global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) alpha[i] = sg_uniform(seed, stream, (uint64_t)i);
+}
+
+// ------------------------------------------------------------------------ forward / rewards
+
+struct DiscFwdArgs {
+    SgDiscDesc d;
+    const float* params;
+    const float* x;   // [n, F]
+    int n;
+    float offset;
+    float* reward;    // [n]  log(s+1e-7) - log(1-s+1e-7) + offset
+};
+
+static size_t disc_fwd_lds_bytes(const SgDiscDesc& d) {
+    return sizeof(float) * ((size_t)d.total + 32 * d.ldF + 2 * 32 * d.ldH);
+}
+
+__global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 32;
+    const SgDiscDesc& d = a.d;
+    const int tid = threadIdx.x, ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp;
+    float* W = smem;
+    float* X = W + d.total;
+    float* H1 = X + R * ldF;
+    float* H2 = H1 + R * ldH;
+    const float* b1 = W + d.b1;
+    const float* b2 = W + d.b2;
+    const float* w3 = W + d.w3;
+    sg_stage(W, a.params, d.total / 4);
+    for (int base = blockIdx.x * R; base < a.n; base += gridDim.x * R) {
+        __syncthreads();
+        for (int i = tid; i < R * Fp; i += blockDim.x) {
+            const int r = i / Fp, c = i - r * Fp;
+            X[r * ldF + c] = (base + r < a.n && c < d.F) ? a.x[(size_t)(base + r) * d.F + c] : 0.f;
+        }
+        __syncthreads();
+        sg_layer_nt<2>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
+        __syncthreads();
+        sg_layer_nt<2>(H1, ldH, W + d.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = tanhf(v + b2[c]); });
+        __syncthreads();
+        const int r = tid >> 3, sub = tid & 7;
+        float s = 0.f;
+        for (int c = sub; c < Hp; c += 8) s += H2[r * ldH + c] * w3[c];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (sub == 0 && base + r < a.n) {
+            const float sg = sg_sigmoid(s + W[d.b3]);
+            a.reward[base + r] = logf(sg + 1e-7f) - logf(1.f - sg + 1e-7f) + a.offset;  // a2c/algo/gail.py:204-205
+        }
+    }
+}
+
+// returns = returns*gamma*masks + reward (first call: returns = reward)   a2c/algo/gail.py:206-209
+__global__ void k_returns_step(float* returns, const float* reward, const float* masks, float gamma, int first, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) returns[i] = first ? reward[i] : returns[i] * gamma * masks[i] + reward[i];
+}
+
+// Per-column scan over T of the same recurrence; keeps every step's returns for the statistics.
+__global__ void k_returns_scan(float* d_returns, const float* raw /*[T,N]*/, const float* masks /*[T+1,N]*/,
+                               float gamma, int first, int T, int N, float* rets /*[T,N]*/) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float ret = first ? 0.f : d_returns[n];
+    for (int t = 0; t < T; ++t) {
+        const float r = raw[(size_t)t * N + n];
+        ret = (first && t == 0) ? r : ret * gamma * masks[(size_t)t * N + n] + r;
+        rets[(size_t)t * N + n] = ret;
+    }
+    d_returns[n] = ret;
+}
+
+// per-step batch sums (pass 0) and sums of squares about the batch mean (pass 1); one block per t
+__global__ __launch_bounds__(256) void k_batch_stats(const float* rets, int N, double n_global, double* stats /*[2][T]*/, int pass) {
+    __shared__ double ws[4];
+    const int t = blockIdx.x;
+    const float* x = rets + (size_t)t * N;
+    double s = 0.0;
+    if (pass == 0) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) s += (double)x[i];
+    } else {
+        const float mean = (float)(stats[t] / n_global);   // numpy: float32 batch mean
+        for (int i = threadIdx.x; i < N; i += blockDim.x) { const float dd = x[i] - mean; s += (double)(dd * dd); }
+    }
+    s = sg_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) stats[(size_t)pass * gridDim.x + t] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Sequential Chan merge over t (float64 state) -> per-step scale = sqrt(var_t + 1e-7)
+__global__ void k_rms_scan(const double* stats, int T, double n_global, double* rms /*[3] in/out*/, float* scale /*[T]*/) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double mean = rms[0], var = rms[1], count = rms[2];
+    for (int t = 0; t < T; ++t) {
+        const double bmean = (double)(float)(stats[t] / n_global);
+        const double bvar = (double)(float)(stats[T + t] / n_global);
+        const double delta = bmean - mean, tot = count + n_global;
+        const double new_mean = mean + delta * n_global / tot;
+        const double M2 = var * count + bvar * n_global + delta * delta * count * n_global / tot;
+        mean = new_mean; var = M2 / tot; count = tot;
+        scale[t] = (float)sqrt(var + 1e-7);
+    }
+    rms[0] = mean; rms[1] = var; rms[2] = count;
+}
+
+__global__ void k_normalize_rewards(float* rewards, const float* scale, int T, int N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * N) return;
+    const float v = rewards[i] / scale[i / N];
+    rewards[i] = fminf(fmaxf(v, -10.f), 10.f);
+}
+
+// --------------------------------------------------------------------------------------- API
+
+extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_disc** out) {
+    SG_REQUIRE(ctx && out, "sg_disc_create: NULL argument");
+    SG_REQUIRE(input_dim > 0 && hidden_dim > 0, "sg_disc_create: bad dims");
+    SG_CHECK(hipSetDevice(ctx->device));
+    sg_disc* d = new sg_disc();
+    d->ctx = ctx;
+    d->desc = sg_make_disc_desc(input_dim, hidden_dim);
+    SG_REQUIRE(disc_grad_lds_bytes(d->desc) <= (size_t)ctx->lds_bytes,
+               "sg_disc_create: discriminator (%d x %d) needs %zu bytes of LDS, the CU has %d", input_dim, hidden_dim,
+               disc_grad_lds_bytes(d->desc), ctx->lds_bytes);
+    const size_t tot = d->desc.total;
+    SG_CHECK(hipMalloc((void**)&d->d_params, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&d->d_m, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&d->d_state, sizeof(SgOptState)));
+    SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
+    SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
+    SG_CHECK(hipMemsetAsync(d->d_m, 0, sizeof(float) * tot, ctx->stream));
+    SG_CHECK(hipMemsetAsync(d->d_v, 0, sizeof(float) * tot, ctx->stream));
+    SgOptState st;
+    memset(&st, 0, sizeof st);
+    st.lr = 1e-3f;
+    SG_CHECK(hipMemcpyAsync(d->d_state, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = d;
+    return 0;
+}
+
+extern "C" int sg_disc_destroy(sg_disc* d) {
+    if (!d) return 0;
+    (void)hipStreamSynchronize(d->ctx->stream);
+    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns};
+    for (float* q : ptrs) if (q) (void)hipFree(q);
+    if (d->d_eperm) (void)hipFree(d->d_eperm);
+    if (d->d_pperm) (void)hipFree(d->d_pperm);
+    if (d->d_loss_acc) (void)hipFree(d->d_loss_acc);
+    delete d;
+    return 0;
+}
+
+extern "C" int sg_disc_num_params(const sg_disc* d, int64_t* n) {
+    SG_REQUIRE(d && n, "sg_disc_num_params: NULL argument");
+    *n = sg_disc_flat_count(d->desc);
+    return 0;
+}
+
+static int disc_put(sg_disc* d, float* dev, const float* flat, int64_t n, const char* who) {
+    SG_REQUIRE(n == sg_disc_flat_count(d->desc), "%s: expected %lld floats, got %lld", who,
+               (long long)sg_disc_flat_count(d->desc), (long long)n);
+    std::vector<float> padded(d->desc.total, 0.f);
+    sg_disc_pad(d->desc, flat, padded.data());
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    SG_CHECK(hipMemcpy(dev, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+static int disc_get(sg_disc* d, const float* dev, float* flat, int64_t n, const char* who) {
+    SG_REQUIRE(n == sg_disc_flat_count(d->desc), "%s: expected %lld floats, got %lld", who,
+               (long long)sg_disc_flat_count(d->desc), (long long)n);
+    std::vector<float> padded(d->desc.total);
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    SG_CHECK(hipMemcpy(padded.data(), dev, sizeof(float) * padded.size(), hipMemcpyDeviceToHost));
+    sg_disc_unpad(d->desc, padded.data(), flat);
+    return 0;
+}
+
+extern "C" int sg_disc_set_params(sg_disc* d, const float* flat, int64_t n) {
+    SG_REQUIRE(d && flat, "sg_disc_set_params: NULL argument");
+    return disc_put(d, d->d_params, flat, n, "sg_disc_set_params");
+}
+extern "C" int sg_disc_get_params(sg_disc* d, float* flat, int64_t n) {
+    SG_REQUIRE(d && flat, "sg_disc_get_params: NULL argument");
+    return disc_get(d, d->d_params, flat, n, "sg_disc_get_params");
+}
+extern "C" int sg_disc_get_adam(sg_disc* d, float* m, float* v, int64_t n, int64_t* step) {
+    SG_REQUIRE(d && m && v && step, "sg_disc_get_adam: NULL argument");
+    SG_TRY(disc_get(d, d->d_m, m, n, "sg_disc_get_adam"));
+    SG_TRY(disc_get(d, d->d_v, v, n, "sg_disc_get_adam"));
+    SgOptState st;
+    SG_CHECK(hipMemcpy(&st, d->d_state, sizeof st, hipMemcpyDeviceToHost));
+    *step = (int64_t)st.step;
+    return 0;
+}
+extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int64_t n, int64_t step) {
+    SG_REQUIRE(d && m && v, "sg_disc_set_adam: NULL argument");
+    SG_TRY(disc_put(d, d->d_m, m, n, "sg_disc_set_adam"));
+    SG_TRY(disc_put(d, d->d_v, v, n, "sg_disc_set_adam"));
+    const float fs = (float)step;
+    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(d->d_state)->step, &fs, sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int sg_disc_set_expert(sg_disc* d, const float* expert, int64_t n_rows) {
+    SG_REQUIRE(d && expert && n_rows > 0, "sg_disc_set_expert: bad argument");
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    if (d->d_expert) SG_CHECK(hipFree(d->d_expert));
+    const size_t bytes = sizeof(float) * (size_t)n_rows * d->desc.F;
+    SG_CHECK(hipMalloc((void**)&d->d_expert, bytes));
+    SG_CHECK(hipMemcpy(d->d_expert, expert, bytes, hipMemcpyHostToDevice));
+    d->n_expert = n_rows;
+    return 0;
+}
+
+template <typename T>
+static int ensure_cap(T** ptr, int64_t* cap, int64_t need, hipStream_t stream) {
+    if (*cap >= need) return 0;
+    SG_CHECK(hipStreamSynchronize(stream));
+    if (*ptr) SG_CHECK(hipFree(*ptr));
+    SG_CHECK(hipMalloc((void**)ptr, sizeof(T) * (size_t)need));
+    *cap = need;
+    return 0;
+}
+
+extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm,
+                                       const int64_t* policy_perm, const float* alpha, uint64_t seed,
+                                       float out3[3], int* n_steps) {
+    SG_REQUIRE(d && r && out3, "sg_disc_update_gail_dyn: NULL argument");
+    sg_ctx* ctx = d->ctx;
+    const SgDiscDesc& dd = d->desc;
+    SG_REQUIRE(d->d_expert, "sg_disc_update_gail_dyn: no expert data (call sg_disc_set_expert first)");
+    SG_REQUIRE(r->F == dd.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, dd.F);
+    SG_REQUIRE(batch_size > 0, "sg_disc_update_gail_dyn: batch_size must be positive");
+    const int world = ctx->world;
+    SG_REQUIRE(batch_size % world == 0, "sg_disc_update_gail_dyn: batch_size %d must divide by world size %d", batch_size, world);
+    const int B_loc = batch_size / world;
+    // the reference's alpha*expert + (1-alpha)*policy raises on a size mismatch when the loader
+    // yields a short batch (a2c/algo/gail.py:75)
+    SG_REQUIRE(d->n_expert >= batch_size, "The size of tensor a (%lld) must match the size of tensor b (%d) at "
+               "non-singleton dimension 0 (expert rows < gail batch size)", (long long)d->n_expert, batch_size);
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int64_t TN = (int64_t)r->T * r->N;
+    const int64_t n_e = d->n_expert / batch_size;   // drop_last (or exactly one full batch)
+    const int64_t n_p = TN / B_loc;                 // local rows contribute batch/world per step
+    const int n_d = (int)(n_e < n_p ? n_e : n_p);
+    SG_REQUIRE(n_d > 0, "sg_disc_update_gail_dyn: rollout (%lld rows) smaller than one batch (%d)", (long long)TN, B_loc);
+    if (n_steps) *n_steps = n_d;
+
+    SG_TRY(ensure_cap(&d->d_eperm, &d->eperm_cap, d->n_expert, ctx->stream));
+    SG_TRY(ensure_cap(&d->d_pperm, &d->pperm_cap, TN, ctx->stream));
+    SG_TRY(ensure_cap(&d->d_alpha, &d->alpha_cap, (int64_t)n_d * batch_size, ctx->stream));
+    d->rng_calls += 1;
+    // expert permutation / alpha are GLOBAL (identical on every rank); the policy permutation is per rank
+    if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
+    else SG_TRY(sg_fill_perm(ctx, d->d_eperm, d->n_expert, seed, 0xE0000000ull + d->rng_calls));
+    if (policy_perm) SG_CHECK(hipMemcpyAsync(d->d_pperm, policy_perm, sizeof(int64_t) * TN, hipMemcpyHostToDevice, ctx->stream));
+    else SG_TRY(sg_fill_perm(ctx, d->d_pperm, TN, seed, 0xF0000000ull + d->rng_calls * 1024 + (uint64_t)ctx->rank));
+    if (alpha) SG_CHECK(hipMemcpyAsync(d->d_alpha, alpha, sizeof(float) * (size_t)n_d * batch_size, hipMemcpyHostToDevice, ctx->stream));
+    else {
+        const int64_t na = (int64_t)n_d * batch_size;
+        hipLaunchKernelGGL(k_fill_alpha, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream, d->d_alpha, na,
+                           seed, 0xA1000000ull + d->rng_calls);
+    }
+
+    const int G = (B_loc + 15) / 16;
+    const int slab_stride = dd.total + 8;
+    if (d->n_slabs < 2 * G + 1) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
+        SG_CHECK(hipMalloc((void**)&d->d_slabs, sizeof(float) * (size_t)(2 * G + 1) * slab_stride));
+        d->n_slabs = 2 * G + 1;
+        SG_CHECK(hipMemsetAsync(d->d_slabs, 0, sizeof(float) * (size_t)(2 * G + 1) * slab_stride, ctx->stream));
+    }
+    SG_CHECK(hipMemsetAsync(d->d_loss_acc, 0, sizeof(double) * 3, ctx->stream));
+
+    DiscArgs a;
+    a.d = dd; a.params = d->d_params; a.expert = d->d_expert;
+    a.next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
+    a.B = B_loc; a.G = G; a.inv_B = 1.0f / (float)batch_size; a.lambda_ = 10.0f;
+    a.slabs = d->d_slabs; a.slab_stride = slab_stride; a.st = reinterpret_cast<SgOptState*>(d->d_state);
+    const size_t lds = disc_grad_lds_bytes(dd);
+    const int nblk = (dd.total + 255) / 256;
+    float* grad = d->d_slabs + (size_t)(2 * G) * slab_stride;   // data-parallel: reduced gradient "slab"
+    for (int k = 0; k < n_d; ++k) {
+        // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
+        a.eperm = d->d_eperm + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
+        a.alpha = d->d_alpha + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
+        a.pperm = d->d_pperm + (size_t)k * B_loc;
+        sg_prof_begin(ctx, SG_PROF_DISC_GRAD);
+        hipLaunchKernelGGL(k_disc_grad, dim3(2 * G), dim3(256), lds, ctx->stream, a);
+        sg_prof_end(ctx, SG_PROF_DISC_GRAD);
+        if (world > 1) {
+            hipLaunchKernelGGL(k_slab_sum, dim3((slab_stride + 255) / 256), dim3(256), 0, ctx->stream, d->d_slabs, 2 * G,
+                               slab_stride, slab_stride, grad);
+            SG_TRY(sg_comm_allreduce_f32(ctx, grad, slab_stride));
+        }
+        sg_prof_begin(ctx, SG_PROF_DISC_ADAM);
+        hipLaunchKernelGGL(k_disc_adam, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v,
+                           world > 1 ? grad : d->d_slabs, world > 1 ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
+                           a.inv_B, a.lambda_, d->d_loss_acc);
+        sg_prof_end(ctx, SG_PROF_DISC_ADAM);
+    }
+    SG_CHECK(hipGetLastError());
+    double acc[3];
+    SG_CHECK(hipMemcpyAsync(acc, d->d_loss_acc, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / n_d);
+    return 0;
+}
+
+static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward) {
+    sg_ctx* ctx = d->ctx;
+    DiscFwdArgs f;
+    f.d = d->desc; f.params = d->d_params; f.x = d_x; f.n = n; f.offset = offset; f.reward = d_reward;
+    int grid = (n + 31) / 32;
+    if (grid > 2 * ctx->num_cu) grid = 2 * ctx->num_cu;
+    sg_prof_begin(ctx, SG_PROF_RELABEL);
+    hipLaunchKernelGGL(k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), ctx->stream, f);
+    sg_prof_end(ctx, SG_PROF_RELABEL);
+    SG_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int ensure_returns(sg_disc* d, int n) {
+    if (d->d_returns && d->returns_n == n) return 0;
+    SG_REQUIRE(d->returns_none || d->returns_n == n,
+               "Discriminator.returns holds %d rows but %d were passed (the reference would broadcast-fail)", d->returns_n, n);
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    if (d->d_returns) SG_CHECK(hipFree(d->d_returns));
+    SG_CHECK(hipMalloc((void**)&d->d_returns, sizeof(float) * n));
+    SG_CHECK(hipMemsetAsync(d->d_returns, 0, sizeof(float) * n, d->ctx->stream));
+    d->returns_n = n;
+    return 0;
+}
+
+extern "C" int sg_disc_predict_reward(sg_disc* d, const float* x, int n, float gamma, const float* masks,
+                                      float offset, float* reward, float* returns) {
+    SG_REQUIRE(d && x && masks && reward && returns && n > 0, "sg_disc_predict_reward: bad argument");
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    SG_TRY(ensure_returns(d, n));
+    float* scratch = nullptr;
+    const size_t fx = (size_t)n * d->desc.F;
+    SG_TRY(sg_ctx_scratch(ctx, sizeof(float) * (fx + 2 * (size_t)n), &scratch));
+    float* d_x = scratch;
+    float* d_masks = d_x + fx;
+    float* d_rew = d_masks + n;
+    SG_CHECK(hipMemcpyAsync(d_x, x, sizeof(float) * fx, hipMemcpyHostToDevice, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(d_masks, masks, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    SG_TRY(disc_forward_dev(d, d_x, n, offset, d_rew));
+    hipLaunchKernelGGL(k_returns_step, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d->d_returns, d_rew, d_masks,
+                       gamma, d->returns_none ? 1 : 0, n);
+    SG_CHECK(hipGetLastError());
+    d->returns_none = false;
+    SG_CHECK(hipMemcpyAsync(reward, d_rew, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(returns, d->d_returns, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_disc_reset_returns(sg_disc* d) {
+    SG_REQUIRE(d, "sg_disc_reset_returns: NULL argument");
+    d->returns_none = true;
+    return 0;
+}
+
+extern "C" int sg_disc_get_returns(sg_disc* d, float* returns, int n, int* is_none) {
+    SG_REQUIRE(d && is_none, "sg_disc_get_returns: NULL argument");
+    *is_none = d->returns_none ? 1 : 0;
+    if (d->returns_none || !returns) return 0;
+    SG_REQUIRE(n == d->returns_n, "sg_disc_get_returns: holds %d rows, asked for %d", d->returns_n, n);
+    SG_CHECK(hipMemcpyAsync(returns, d->d_returns, sizeof(float) * n, hipMemcpyDeviceToHost, d->ctx->stream));
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_disc_set_returns(sg_disc* d, const float* returns, int n) {
+    SG_REQUIRE(d && returns && n > 0, "sg_disc_set_returns: bad argument");
+    d->returns_none = true;
+    SG_TRY(ensure_returns(d, n));
+    SG_CHECK(hipMemcpyAsync(d->d_returns, returns, sizeof(float) * n, hipMemcpyHostToDevice, d->ctx->stream));
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    d->returns_none = false;
+    return 0;
+}
+
+extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, float offset, double rms_state[3]) {
+    SG_REQUIRE(d && r && rms_state, "sg_disc_relabel_rewards: NULL argument");
+    sg_ctx* ctx = d->ctx;
+    SG_REQUIRE(r->F == d->desc.F, "sg_disc_relabel_rewards: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int T = r->T, N = r->N;
+    const int64_t TN = (int64_t)T * N;
+    SG_TRY(ensure_returns(d, N));
+    // scratch: rets [T,N] | stats [2][T] doubles | rms [3] doubles | scale [T]
+    float* scratch = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)TN + sizeof(double) * (2 * (size_t)T + 4) + sizeof(float) * T + 64;
+    SG_TRY(sg_ctx_scratch(ctx, bytes, &scratch));
+    float* rets = scratch;
+    double* stats = reinterpret_cast<double*>(scratch + ((TN + 3) & ~(int64_t)3));
+    double* rms = stats + 2 * (size_t)T;
+    float* scale = reinterpret_cast<float*>(rms + 4);
+    SG_CHECK(hipMemcpyAsync(rms, rms_state, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
+    float* rewards = r->d_field[SG_F_REWARDS];
+    // rewards[t] <- D(obs_feat[t+1]) (+offset): rows t*N+n of obs_feat[1:]
+    SG_TRY(disc_forward_dev(d, r->d_field[SG_F_OBS_FEAT] + (size_t)N * r->F, (int)TN, offset, rewards));
+    hipLaunchKernelGGL(k_returns_scan, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, d->d_returns, rewards,
+                       r->d_field[SG_F_MASKS], gamma, d->returns_none ? 1 : 0, T, N, rets);
+    d->returns_none = false;
+    const double n_global = (double)N * ctx->world;
+    hipLaunchKernelGGL(k_batch_stats, dim3(T), dim3(256), 0, ctx->stream, rets, N, n_global, stats, 0);
+    if (ctx->world > 1) SG_TRY(sg_comm_allreduce_f64(ctx, stats, T));            // per-step sums over all ranks
+    hipLaunchKernelGGL(k_batch_stats, dim3(T), dim3(256), 0, ctx->stream, rets, N, n_global, stats, 1);
+    if (ctx->world > 1) SG_TRY(sg_comm_allreduce_f64(ctx, stats + T, T));        // squares about the global mean
+    hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(1), 0, ctx->stream, stats, T, n_global, rms, scale);
+    hipLaunchKernelGGL(k_normalize_rewards, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, ctx->stream, rewards, scale, T, N);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipMemcpyAsync(rms_state, rms, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

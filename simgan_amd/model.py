@@ -1,0 +1,191 @@
+"""Policy -- host mirror of a2c/model.py:37-114 (MLPBase + DiagGaussian, Box actions,
+non-recurrent).  Parameters live in HBM inside libsimgan_hip.so; this class keeps the
+reference's constructor and method signatures and hands host tensors across the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .utils import orthogonal, to_host_tensor
+
+
+class _PolicyBase(object):
+    KIND = None
+
+    def _create(self, obs_dim, act_dim, hidden, num_feet, ctx):
+        self.ctx = ctx or _lib.Context.default()
+        self.lib = self.ctx.lib
+        self.obs_dim, self.act_dim = int(obs_dim), int(act_dim)
+        self.hidden_size, self.num_feet = int(hidden), int(num_feet)
+        h = _lib.H()
+        _lib.check(self.lib.sg_policy_create(self.ctx.h, self.KIND, self.obs_dim, self.act_dim,
+                                             self.hidden_size, self.num_feet, C.byref(h)))
+        self.h = h
+        n = C.c_int64(0)
+        _lib.check(self.lib.sg_policy_num_params(self.h, C.byref(n)))
+        self.num_params = n.value
+        self._seed = 0x5EED
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.sg_policy_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- nn.Module-ish surface the reference mains touch
+    @property
+    def is_recurrent(self):
+        return False
+
+    @property
+    def recurrent_hidden_state_size(self):
+        """Size of rnn_hx."""
+        return 1
+
+    def to(self, device):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        """One flat host tensor (a copy): enough for `next(p.parameters())`-style probes."""
+        yield to_host_tensor(self.get_flat_params())
+
+    def forward(self, inputs, rnn_hxs, masks):
+        raise NotImplementedError
+
+    # ---- flat parameter access (torch state_dict order, see oracle/sg_oracle.c header)
+    def get_flat_params(self):
+        out = np.empty(self.num_params, np.float32)
+        _lib.check(self.lib.sg_policy_get_params(self.h, _lib.fptr(out), out.size))
+        return out
+
+    def set_flat_params(self, flat):
+        flat = _lib.as_f32(flat).reshape(-1)
+        _lib.check(self.lib.sg_policy_set_params(self.h, _lib.fptr(flat), flat.size))
+
+    def state_dict(self):
+        flat, out, off = self.get_flat_params(), {}, 0
+        for name, shape in self.param_shapes():
+            n = int(np.prod(shape))
+            out[name] = to_host_tensor(flat[off:off + n].reshape(shape).copy())
+            off += n
+        return out
+
+    def load_state_dict(self, sd):
+        parts = []
+        for name, shape in self.param_shapes():
+            a = _lib.as_f32(sd[name])
+            assert tuple(a.shape) == tuple(shape), (name, a.shape, shape)
+            parts.append(a.reshape(-1))
+        self.set_flat_params(np.concatenate(parts))
+
+    def __getstate__(self):
+        return {"obs_dim": self.obs_dim, "act_dim": self.act_dim, "hidden": self.hidden_size,
+                "num_feet": self.num_feet, "flat": self.get_flat_params()}
+
+    def __setstate__(self, st):
+        self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None)
+        self.set_flat_params(st["flat"])
+
+    # ---- the three calls on the hot path
+    def act(self, inputs, rnn_hxs, masks, deterministic=False, noise=None):
+        """a2c/model.py:89-101 -> (value [n,1], action [n,A], action_log_probs [n,1], rnn_hxs).
+        `noise` ([n,A] standard normal) injects the sampling draw; default = library RNG."""
+        obs = _lib.as_f32(inputs).reshape(-1, self.obs_dim)
+        n = obs.shape[0]
+        value = np.empty((n, 1), np.float32)
+        action = np.empty((n, self.act_dim), np.float32)
+        logp = np.empty((n, 1), np.float32)
+        nz = None if noise is None else _lib.as_f32(noise).reshape(n, self.act_dim)
+        self._seed += 1
+        _lib.check(self.lib.sg_policy_act(self.h, _lib.fptr(obs), n,
+                                          None if nz is None else _lib.fptr(nz), self._seed,
+                                          1 if deterministic else 0, _lib.fptr(value),
+                                          _lib.fptr(action), _lib.fptr(logp)))
+        return to_host_tensor(value), to_host_tensor(action), to_host_tensor(logp), rnn_hxs
+
+    def get_value(self, inputs, rnn_hxs, masks):
+        """a2c/model.py:103-105"""
+        obs = _lib.as_f32(inputs).reshape(-1, self.obs_dim)
+        value = np.empty((obs.shape[0], 1), np.float32)
+        _lib.check(self.lib.sg_policy_get_value(self.h, _lib.fptr(obs), obs.shape[0], _lib.fptr(value)))
+        return to_host_tensor(value)
+
+    def evaluate_actions(self, inputs, rnn_hxs, masks, action):
+        """a2c/model.py:107-114 -> (value, action_log_probs, dist_entropy, rnn_hxs)"""
+        obs = _lib.as_f32(inputs).reshape(-1, self.obs_dim)
+        n = obs.shape[0]
+        act = _lib.as_f32(action).reshape(n, self.act_dim)
+        value = np.empty((n, 1), np.float32)
+        logp = np.empty((n, 1), np.float32)
+        ent = C.c_float(0)
+        _lib.check(self.lib.sg_policy_evaluate(self.h, _lib.fptr(obs), _lib.fptr(act), n,
+                                               _lib.fptr(value), _lib.fptr(logp), C.byref(ent)))
+        ent_t = to_host_tensor(np.array(ent.value, np.float32))
+        return to_host_tensor(value), to_host_tensor(logp), ent_t, rnn_hxs
+
+
+class Policy(_PolicyBase):
+    KIND = _lib.POLICY_MLP
+
+    def __init__(self, obs_shape, action_space, base=None, base_kwargs=None, ctx=None, seed=0):
+        if base_kwargs is None:
+            base_kwargs = {}
+        if base is not None or len(obs_shape) != 1:
+            raise NotImplementedError("only the MLP base on 1-D observations is built (SURVEY.md section 2, row 3)")
+        if base_kwargs.get("recurrent", False):
+            raise NotImplementedError("recurrent policies are not used by any shipped SimGAN config")
+        if action_space.__class__.__name__ != "Box":
+            raise NotImplementedError("only Box action spaces (a2c/model.py:55-57)")
+        hidden = base_kwargs.get("hidden_size", 64)
+        self._create(obs_shape[0], action_space.shape[0], hidden, 1, ctx)
+        self._init_params(np.random.default_rng(seed))
+
+    def param_shapes(self):
+        O, A, Hh = self.obs_dim, self.act_dim, self.hidden_size
+        return [("base.actor.0.weight", (Hh, O)), ("base.actor.0.bias", (Hh,)),
+                ("base.actor.2.weight", (Hh, Hh)), ("base.actor.2.bias", (Hh,)),
+                ("base.critic.0.weight", (Hh, O)), ("base.critic.0.bias", (Hh,)),
+                ("base.critic.2.weight", (Hh, Hh)), ("base.critic.2.bias", (Hh,)),
+                ("base.critic_linear.weight", (1, Hh)), ("base.critic_linear.bias", (1,)),
+                ("dist.fc_mean.weight", (A, Hh)), ("dist.fc_mean.bias", (A,)),
+                ("dist.logstd._bias", (A, 1))]
+
+    def _init_params(self, rng):
+        """a2c/model.py:240-251 (orthogonal, gain sqrt2, zero bias), a2c/distributions.py:95-104
+        (fc_mean gain 1 then /50, logstd -0.5)."""
+        sd = {}
+        for name, shape in self.param_shapes():
+            if name.endswith("logstd._bias"):
+                sd[name] = np.full(shape, -0.5, np.float32)
+            elif name.endswith("bias"):
+                sd[name] = np.zeros(shape, np.float32)
+            elif name.startswith("dist.fc_mean"):
+                sd[name] = orthogonal(rng, *shape, gain=1.0) / 50.0
+            else:
+                sd[name] = orthogonal(rng, *shape, gain=np.sqrt(2))
+        self.load_state_dict(sd)
+
+    def reset_variance(self, action_space, log_std):
+        """a2c/model.py:76-78"""
+        sd = self.state_dict()
+        sd["dist.logstd._bias"] = np.full((action_space.shape[0], 1), log_std, np.float32)
+        self.load_state_dict(sd)
+
+    def reset_critic(self, obs_shape, seed=1):
+        """a2c/model.py:80-87 (the reference hard-codes a 64-unit critic; here the critic keeps
+        the policy's hidden size, which is 64 for every config that calls this)."""
+        rng = np.random.default_rng(seed)
+        sd = self.state_dict()
+        for name, shape in self.param_shapes():
+            if name.startswith("base.critic"):
+                sd[name] = (np.zeros(shape, np.float32) if name.endswith("bias")
+                            else orthogonal(rng, *shape, gain=np.sqrt(2)))
+        self.load_state_dict(sd)

@@ -1,0 +1,172 @@
+"""RolloutStorage -- host mirror of a2c/storage.py:31-192 with a device-resident twin.
+
+The reference mains read and write the buffers by slicing (`rollouts.obs[0].copy_(obs)`,
+`rollouts.rewards[step] = ...`), so the attributes stay ordinary host tensors with the
+reference's shapes.  The HBM copy inside libsimgan_hip.so is refreshed per operation:
+  * default (drop-in) mode: every device operation first uploads the fields it reads and
+    downloads the fields it writes -- PCIe-inclusive, always coherent with host-side edits;
+  * `device_resident = True` (driver / bench fast path): uploads are skipped, the device copy is
+    the source of truth and `sync_from_device()` refreshes the host view on demand.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .utils import to_host_tensor, torch
+
+_FIELD_ATTR = {
+    _lib.F_OBS: "obs", _lib.F_OBS_FEAT: "obs_feat", _lib.F_ACTIONS: "actions",
+    _lib.F_REWARDS: "rewards", _lib.F_VALUE_PREDS: "value_preds", _lib.F_RETURNS: "returns",
+    _lib.F_LOGP: "action_log_probs", _lib.F_MASKS: "masks", _lib.F_BAD_MASKS: "bad_masks",
+}
+
+
+class RolloutStorage(object):
+    def __init__(self, num_steps, num_processes, obs_shape, action_space,
+                 recurrent_hidden_state_size, feat_len=0, ctx=None):
+        T, N = int(num_steps), int(num_processes)
+        if action_space.__class__.__name__ == 'Discrete':
+            raise NotImplementedError("discrete action spaces never occur in SimGAN configs")
+        if len(obs_shape) != 1:
+            raise NotImplementedError("1-D observations only")
+        O, A, F = int(obs_shape[0]), int(action_space.shape[0]), int(feat_len)
+        z = lambda *s: to_host_tensor(np.zeros(s, np.float32))  # noqa: E731
+        o = lambda *s: to_host_tensor(np.ones(s, np.float32))  # noqa: E731
+        self.obs = z(T + 1, N, O)
+        self.obs_feat = z(T + 1, N, F)
+        self.recurrent_hidden_states = z(T + 1, N, recurrent_hidden_state_size)
+        self.rewards = z(T, N, 1)
+        self.value_preds = z(T + 1, N, 1)
+        self.returns = z(T + 1, N, 1)
+        self.action_log_probs = z(T, N, 1)
+        self.actions = z(T, N, A)
+        self.masks = o(T + 1, N, 1)
+        # Masks that indicate whether it's a true terminal state or time limit end state
+        self.bad_masks = o(T + 1, N, 1)
+        self.num_steps = T
+        self.num_processes = N
+        self.step = 0
+        self.obs_dim, self.act_dim, self.feat_len = O, A, F
+        self.device_resident = False
+
+        self.ctx = ctx or _lib.Context.default()
+        self.lib = self.ctx.lib
+        h = _lib.H()
+        _lib.check(self.lib.sg_rollout_create(self.ctx.h, T, N, O, A, F, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.sg_rollout_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def to(self, device):
+        return None  # host tensors stay on the host; the HBM twin lives in the library
+
+    # ----------------------------------------------------------------- host <-> device
+    def _host_np(self, field):
+        t = getattr(self, _FIELD_ATTR[field])
+        a = t.numpy() if hasattr(t, "numpy") else t
+        if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError(f"rollouts.{_FIELD_ATTR[field]} must stay a contiguous float32 host tensor")
+        return a
+
+    def sync_to_device(self, fields=None):
+        for f in (fields if fields is not None else _FIELD_ATTR):
+            a = self._host_np(f)
+            if a.size:
+                _lib.check(self.lib.sg_rollout_upload(self.h, f, _lib.fptr(a), a.size))
+
+    def sync_from_device(self, fields=None):
+        for f in (fields if fields is not None else _FIELD_ATTR):
+            a = self._host_np(f)
+            if a.size:
+                _lib.check(self.lib.sg_rollout_download(self.h, f, _lib.fptr(a), a.size))
+
+    def _push(self, fields):
+        if not self.device_resident:
+            self.sync_to_device(fields)
+
+    def _pull(self, fields):
+        if not self.device_resident:
+            self.sync_from_device(fields)
+
+    def device_advantages(self):
+        out = np.empty((self.num_steps, self.num_processes, 1), np.float32)
+        _lib.check(self.lib.sg_rollout_download(self.h, _lib.F_ADVANTAGES, _lib.fptr(out), out.size))
+        return to_host_tensor(out)
+
+    # ------------------------------------------------------------- reference methods
+    def insert(self, obs, recurrent_hidden_states, actions, action_log_probs,
+               value_preds, rewards, masks, bad_masks, obs_feat=None):
+        """a2c/storage.py:70-84"""
+        s = self.step
+
+        def put(dst, src):
+            if torch is not None and hasattr(dst, "copy_"):
+                dst.copy_(src if hasattr(src, "dim") else torch.as_tensor(np.asarray(src, np.float32)))
+            else:
+                dst[...] = np.asarray(src, np.float32)
+
+        put(self.obs[s + 1], obs)
+        if obs_feat is not None:
+            put(self.obs_feat[s + 1], obs_feat)
+        put(self.recurrent_hidden_states[s + 1], recurrent_hidden_states)
+        put(self.actions[s], actions)
+        put(self.action_log_probs[s], action_log_probs)
+        put(self.value_preds[s], value_preds)
+        put(self.rewards[s], rewards)
+        put(self.masks[s + 1], masks)
+        put(self.bad_masks[s + 1], bad_masks)
+        self.step = (self.step + 1) % self.num_steps
+
+    def after_update(self):
+        """a2c/storage.py:96-101"""
+        for name in ("obs", "obs_feat", "recurrent_hidden_states", "masks", "bad_masks"):
+            t = getattr(self, name)
+            t[0] = t[-1]
+        if self.device_resident:
+            _lib.check(self.lib.sg_rollout_after_update(self.h))
+
+    def compute_returns(self, next_value, use_gae, gamma, gae_lambda, use_proper_time_limits=True):
+        """a2c/storage.py:103-142, on device (one thread per env column, reverse scan over T)."""
+        self._push([_lib.F_REWARDS, _lib.F_VALUE_PREDS, _lib.F_RETURNS, _lib.F_MASKS, _lib.F_BAD_MASKS])
+        nv = _lib.as_f32(next_value).reshape(-1)
+        assert nv.size == self.num_processes
+        _lib.check(self.lib.sg_rollout_compute_returns(self.h, _lib.fptr(nv), 1 if use_gae else 0,
+                                                       float(gamma), float(gae_lambda),
+                                                       1 if use_proper_time_limits else 0))
+        self._pull([_lib.F_RETURNS, _lib.F_VALUE_PREDS])
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        """a2c/storage.py:144-192 -- host-side generator kept for API completeness (the device
+        PPO / discriminator updates gather rows themselves and do not use it)."""
+        num_steps, num_processes = self.rewards.shape[0:2]
+        batch_size = num_processes * num_steps
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch, (
+                "PPO requires the number of processes ({}) "
+                "* number of steps ({}) = {} "
+                "to be greater than or equal to the number of PPO mini batches ({})."
+                "".format(num_processes, num_steps, num_processes * num_steps, num_mini_batch))
+            mini_batch_size = batch_size // num_mini_batch
+        perm = np.random.permutation(batch_size)
+
+        def flat(t, sl):
+            a = t.numpy() if hasattr(t, "numpy") else t
+            a = a[sl]
+            return a.reshape(-1, a.shape[-1])
+
+        cur, nxt, al = slice(None, -1), slice(1, None), slice(None)
+        for k in range(batch_size // mini_batch_size):  # drop_last
+            idx = perm[k * mini_batch_size:(k + 1) * mini_batch_size]
+            g = lambda t, sl: to_host_tensor(np.ascontiguousarray(flat(t, sl)[idx]))  # noqa: E731
+            adv = None if advantages is None else to_host_tensor(
+                np.ascontiguousarray(_lib.as_f32(advantages).reshape(-1, 1)[idx]))
+            yield (g(self.obs, cur), g(self.recurrent_hidden_states, cur), g(self.actions, al),
+                   g(self.value_preds, cur), g(self.returns, cur), g(self.masks, cur),
+                   g(self.action_log_probs, al), adv, g(self.obs_feat, cur), g(self.obs_feat, nxt))
