@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the GAIL-dyn PPO update on MI355X.
+
+One "step" = one full update of the reference's outer loop body on an already-collected synthetic
+rollout (a2c/main_gail_dyn_ppo.py:255-302, a2c/ = third_party/a2c_ppo_acktr/):
+    gail_epoch x Discriminator.update_gail_dyn  ->  alive-bonus offset  ->  T x predict_reward
+    (+ return normalisation)  ->  compute_returns (GAE)  ->  PPO.update
+Inputs (rollout, expert matrix, weights, optimizer state) are resident in HBM before the timed
+region starts; nothing is skipped inside it.
+
+    python bench.py --gpus N --steps K --warmup W [--workload northstar|hopper|laikago]
+
+N > 1: launched by torch.distributed.run, one process per GPU; control plane (barrier, id
+broadcast, max-over-ranks) on gloo, data plane (gradient all-reduce) on RCCL inside the library.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json north_star synthetic shape; BASELINE.md section 4 prices this one
+    "northstar": dict(kind="mlp", T=128, N=512, O=47, A=12, F=86, H=64, feet=1, Hd=100, E_p=10, M=16, E_d=5,
+                      B=128, Ne=100000, clip=0.2),
+    # BASELINE.json configs[1]: HopperCombinedEnv-v1 GAIL-dyn, num_processes=256, SplitPolicy h100 as shipped
+    "hopper": dict(kind="split", T=128, N=256, O=14, A=7, F=25, H=100, feet=1, Hd=100, E_p=10, M=16, E_d=5,
+                   B=128, Ne=100000, clip=0.2),
+    # BASELINE.json configs[2] real shapes: LaikagoCombinedEnv-v1, SplitPolicy h100 nf=4
+    "laikago": dict(kind="split", T=128, N=512, O=64, A=28, F=86, H=100, feet=4, Hd=100, E_p=10, M=16, E_d=5,
+                    B=128, Ne=100000, clip=0.2),
+}
+GAMMA, LAM = 0.99, 0.95
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+class Box:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class Loader:
+    def __init__(self, expert, batch_size):
+        self.expert, self.batch_size = expert, batch_size
+
+
+def algorithmic_work(w, world):
+    """Per-update algorithmic FLOPs and HBM bytes for ONE rank (SURVEY.md 8(d) formulas)."""
+    T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
+    TN = T * N
+    n_d = min(w["Ne"] // B, TN * world // B)
+    Wd = F * Hd + Hd * Hd + Hd
+    d_flops_triple = 2 * (8 * Wd + F * Hd + 4 * Hd * Hd + Hd)
+    if w["kind"] == "mlp":
+        fwd = 2 * (O * H + H * H) + H + H * A
+        n_tr = 2
+    else:
+        fwd = 3 * (O * H + H * H) + H + 2 * H * A
+        n_tr = 3
+    ppo_flops_row = 2 * (3 * fwd - n_tr * O * H)
+    mb = TN // w["M"]
+    d_step_flops = (B // world) * d_flops_triple
+    ppo_step_flops = mb * ppo_flops_row
+    relabel_flops = TN * 2 * Wd
+    flops = w["E_d"] * n_d * d_step_flops + w["E_p"] * w["M"] * ppo_step_flops + relabel_flops
+    bytes_ = (w["E_d"] * n_d * 2 * (B // world) * F * 4 + TN * (F + 2) * 4 + TN * 20 + TN * 12 +
+              w["E_p"] * w["M"] * mb * (O + A + 4) * 4)
+    return dict(n_d=n_d, d_step_flops=d_step_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
+                d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"])
+
+
+def build_problem(sg, w, seed):
+    rng = np.random.default_rng(seed)
+    if w["kind"] == "mlp":
+        pol = sg.Policy((w["O"],), Box((w["A"],)), base_kwargs={"recurrent": False, "hidden_size": w["H"]}, seed=seed)
+    else:
+        pol = sg.SplitPolicy((w["O"],), Box((w["A"],)), base_kwargs={"hidden_size": w["H"], "num_feet": w["feet"]}, seed=seed)
+    disc = sg.algo.gail.Discriminator(w["F"], w["Hd"], None, seed=seed)
+    agent = sg.algo.PPO(pol, w["clip"], w["E_p"], w["M"], 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    ro = sg.RolloutStorage(w["T"], w["N"], (w["O"],), Box((w["A"],)), 1, w["F"])
+    ro.device_resident = True
+    expert = rng.standard_normal((w["Ne"], w["F"])).astype(np.float32)   # identical on every rank (same seed)
+    disc.set_expert(expert)
+    loader = Loader(None, w["B"])
+    disc._expert_id = id(loader)  # expert already resident
+    return pol, disc, agent, ro, loader, expert
+
+
+def one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world, gail_tar_length=500.0):
+    import ctypes as C
+    from simgan_amd import _lib
+    losses_d = None
+    for _ in range(w["E_d"]):
+        losses_d = disc.update_gail_dyn(loader, ro)
+    dones = C.c_double(0)
+    _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))
+    n_tot = w["N"] * world
+    num_of_dones = dones.value + n_tot / 2
+    d_sa = 1 - num_of_dones / (num_of_dones + (w["T"] * n_tot) / gail_tar_length)
+    r_sa = np.log(d_sa) - np.log(1 - d_sa)
+    disc.relabel_rewards(ro, GAMMA, -r_sa, rms)
+    _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, GAMMA, LAM, 1))
+    losses_p = agent.update(ro)
+    return losses_d, losses_p
+
+
+def cpu_baseline(w, expert, budget_s):
+    """Times the CPU oracle (oracle/sg_oracle.c, kind "port") single-threaded on a bounded sample of
+    the same workload and scales to a full update."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1)
+    T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
+    work = algorithmic_work(w, 1)
+    # --- discriminator steps
+    dpar = (rng.standard_normal(orc.disc_num_params(F, Hd)) * 0.1).astype(np.float32)
+    adam = orc.AdamState(dpar.size)
+    e = expert[:B]
+    p = rng.standard_normal((B, F)).astype(np.float32)
+    al = rng.random(B).astype(np.float32)
+    n_dsteps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s * 0.6 or n_dsteps < 2:
+        G, _ = orc.disc_grad_rows(F, Hd, dpar, e, p, al, 1.0 / B)
+        orc.adam_step(dpar, G, adam, 1e-3, 1e-8)
+        n_dsteps += 1
+    t_d = (time.perf_counter() - t0) / n_dsteps
+    # --- PPO minibatch steps on a row sample
+    kind = orc.KIND_MLP if w["kind"] == "mlp" else orc.KIND_SPLIT
+    d = orc.dims(kind, O, A, H, w["feet"])
+    ppar = (rng.standard_normal(orc.policy_num_params(d)) * 0.1).astype(np.float32)
+    padam = orc.AdamState(ppar.size)
+    mb = T * N // w["M"]
+    rows_s = min(mb, 512)
+    obs = rng.standard_normal((rows_s, O)).astype(np.float32)
+    act = rng.standard_normal((rows_s, A)).astype(np.float32)
+    z = rng.standard_normal((4, rows_s)).astype(np.float32)
+    cfg = orc.ppo_cfg(w["clip"], 1, 1, 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
+    n_p, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s * 0.3 or n_p < 1:
+        G, _ = orc.ppo_grad_rows(d, ppar, cfg, obs, act, z[0], z[1], z[2] - 20.0, z[3], np.arange(rows_s), 1.0 / rows_s)
+        orc.ppo_apply(ppar, G, padam, cfg)
+        n_p += 1
+    t_p = (time.perf_counter() - t0) / n_p * (mb / rows_s)
+    # --- relabel forward on a row sample
+    x = rng.standard_normal((2048, F)).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.disc_predict_reward(F, Hd, dpar, x, GAMMA, np.ones(2048, np.float32), 0.0)
+    t_r = (time.perf_counter() - t0) * (T * N / 2048)
+    est = work["d_steps"] * t_d + work["ppo_steps"] * t_p + t_r
+    return dict(value=round(T * N / est, 1), unit="env-steps/s", cores=1, kind="port",
+                sample=(f"{n_dsteps} discriminator steps (batch {B}) + {n_p} PPO steps on {rows_s}-row minibatch samples + "
+                        f"2048-row relabel forward, scaled to {work['d_steps']} + {work['ppo_steps']} steps per update; "
+                        f"{1e3 * t_d:.2f} ms/D-step, {1e3 * t_p:.1f} ms/PPO-step"),
+                reference_pytorch_cpu_env_steps_s=4627.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import simgan_amd as sg
+    from simgan_amd import _lib
+    ctx = _lib.Context.default()   # device = LOCAL_RANK
+    lib = ctx.lib
+    if world > 1:
+        ids = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+
+    w = WORKLOADS[args.workload]
+    pol, disc, agent, ro, loader, expert = build_problem(sg, w, seed=0)
+    _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
+    rms = sg.RunningMeanStd(shape=())
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
+    ctx.profile_reset()
+    ctx.profile(True)
+    one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+    ctx.profile(False)
+    prof = {name: ctx.profile_read(i) for i, name in enumerate(
+        ["disc_grad", "disc_adam", "ppo_grad", "ppo_reduce", "ppo_adam", "relabel_fwd"])}
+
+    if rank == 0:
+        work = algorithmic_work(w, world)
+        env_steps = w["T"] * w["N"] * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = env_steps * args.steps / elapsed
+        dg_ms, dg_n = prof["disc_grad"]
+        dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
+        achieved = work["d_step_flops"] / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
+        name, num_cu, hbm = ctx.device_info()
+        out = {
+            "metric": "env-steps/sec of GAIL-dyn PPO update", "value": round(value, 1), "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GAIL-dyn update, T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
+                                   f"D-in={w['F']} policy={w['kind']} h{w['H']} D h{w['Hd']} ppo_epoch={w['E_p']} "
+                                   f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}",
+                       "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
+                       "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "k_disc_grad", "achieved": round(achieved, 3),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
+                         "algorithmic_flops_per_launch": work["d_step_flops"],
+                         "whole_update": {"TFLOP/s": round(work["flops"] * args.steps / elapsed / 1e12, 3),
+                                          "GB/s": round(work["bytes"] * args.steps / elapsed / 1e9, 2),
+                                          "frac_mfma": round(work["flops"] * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
+                                          "frac_hbm": round(work["bytes"] * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 6)}},
+            "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()},
+            "kernel_launches": {k: v[1] for k, v in prof.items()},
+            "us_per_optimizer_step": round(1e3 * ms_per_step / (work["d_steps"] + work["ppo_steps"]), 2),
+            "last_losses": {"disc": last[0], "ppo": last[1]},
+            "device": name, "num_cu": num_cu,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, expert, args.cpu_seconds)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
