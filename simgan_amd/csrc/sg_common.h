@@ -158,15 +158,30 @@ struct sg_disc {
     int returns_n = 0;
     bool returns_none = true;
     uint64_t rng_calls = 0;
+    long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
 };
 
 // Device-side optimizer scalars (float): kept in device memory so captured/queued launches never
 // depend on host-side kernel arguments that change between steps.
 struct SgOptState {
     float lr;
-    float step;      // Adam t (exact in fp32 up to 2^24 steps)
-    float pad[6];
+    float step;       // Adam t (exact in fp32 up to 2^24 steps)
+    float step_size;  // lr / (1 - beta1^t), refreshed by sg_opt_advance()
+    float bc2_sqrt;   // sqrt(1 - beta2^t)
+    float pad[4];
 };
+
+#ifdef __HIPCC__
+// t += 1 and the bias-correction scalars of torch.optim.Adam (Python doubles in torch); called by
+// ONE thread of the kernel that precedes the Adam kernel, so the Adam kernel only reads them.
+__device__ __forceinline__ void sg_opt_advance(SgOptState* st) {
+    const float t = st->step + 1.0f;
+    st->step = t;
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    st->step_size = (float)((double)st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+#endif
 
 // RCCL (sg_comm.cpp)
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n);

@@ -48,20 +48,46 @@ struct DiscArgs {
     float* slabs;
     int slab_stride;
     SgOptState* st;
+    long long* dbg;          // optional phase timestamps [block][32] (test hook), NULL in production
 };
+
+// barrier + (test hook) shader-clock timestamp of the phase that just ended
+#define SG_PHASE_SYNC(n)                                                         \
+    do {                                                                         \
+        __syncthreads();                                                         \
+        if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 32 + (n)] = clock64(); \
+    } while (0)
 
 __device__ __forceinline__ float sg_log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 static size_t disc_grad_lds_bytes(const SgDiscDesc& d) {
-    const size_t bce = (size_t)32 * d.ldF + 2 * 32 * d.ldH + 64;
-    const size_t mix = (size_t)2 * 16 * d.ldF + 6 * 16 * d.ldH + 64;
+    const size_t bce = (size_t)32 * d.ldF + 3 * 32 * d.ldH + 64;
+    const size_t mix = (size_t)2 * 16 * d.ldF + 7 * 16 * d.ldH + 64;
     return sizeof(float) * ((size_t)d.total + (bce > mix ? bce : mix));
 }
 
-__global__ __launch_bounds__(256) void k_disc_grad(DiscArgs a) {
+// sum over the L (power of two, <= 64) consecutive lanes that share a row
+__device__ __forceinline__ float sg_rowlane_sum(float s, int L) {
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+#define SG_DISC_THREADS 512
+
+// KF = pad16(F)/16 and KH = pad16(Hd)/16 as compile-time constants (0 = take them from the
+// descriptor at run time): with the shape fixed, every GEMM extent, LDS offset and staging trip
+// count folds to a constant, the K/N dispatch switches of the tile engine collapse to the one
+// body needed, and the kernel's code shrinks ~6x (it has to stay resident in the 64 KB I-cache).
+template <int KF, int KH>
+__global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_grad(DiscArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const SgDiscDesc& d = a.d;
+    SgDiscDesc d = a.d;
+    if (KF > 0 && KH > 0) {   // same arithmetic as sg_make_disc_desc
+        d.Fp = 16 * KF; d.ldF = d.Fp + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4;
+        d.w1 = 0; d.b1 = d.Hp * d.ldF; d.w2 = d.b1 + d.Hp; d.b2 = d.w2 + d.Hp * d.ldH;
+        d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
+    }
     const int tid = threadIdx.x;
     const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp, F = d.F;
     float* W = smem;
@@ -72,37 +98,49 @@ __global__ __launch_bounds__(256) void k_disc_grad(DiscArgs a) {
     const float* w3 = W + d.w3;
     float* buf = W + d.total;
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    if (blockIdx.x == 0 && tid == 0) a.st->step += 1.0f;  // Adam t for the k_disc_adam that follows
+    if (blockIdx.x == 0 && tid == 0) sg_opt_advance(a.st);  // Adam t for the k_disc_adam that follows
+    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
 
-    sg_stage(W, a.params, d.total / 4);
-
+    const int li = tid & 15, lq = (tid & 63) >> 4;
     if ((int)blockIdx.x < a.G) {
         // ------------------------------------------------ BCE group: rows 0-15 expert, 16-31 policy
         constexpr int R = 32;
         const int g = blockIdx.x;
         float* X = buf;
         float* H1 = X + R * ldF;
-        float* H2 = H1 + R * ldH;
-        float* DD = H2 + R * ldH;
+        float* H2 = H1 + R * ldH;   // h2, then dZ2 in place
+        float* DZ1 = H2 + R * ldH;
+        float* DD = DZ1 + R * ldH;
         float* LOSS = DD + R;
-        for (int i = tid; i < R * Fp; i += blockDim.x) {
-            const int r = i / Fp, c = i - r * Fp;
-            const int b = g * 16 + (r & 15);
-            float v = 0.f;
-            if (b < a.B && c < F)
-                v = (r < 16) ? a.expert[(size_t)a.eperm[b] * F + c] : a.next_feat[(size_t)a.pperm[b] * F + c];
-            X[r * ldF + c] = v;
+        // row gather, 8 elements per lane in flight (index load -> row load are dependent round trips)
+        for (int base = tid; base < R * Fp; base += 8 * blockDim.x) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * blockDim.x;
+                const int r = i / Fp, c = i - r * Fp;
+                const int b = g * 16 + (r & 15);
+                v[u] = 0.f;
+                if (i < R * Fp && b < a.B && c < F)
+                    v[u] = (r < 16) ? a.expert[(size_t)a.eperm[b] * F + c] : a.next_feat[(size_t)a.pperm[b] * F + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * blockDim.x;
+                if (i < R * Fp) X[(i / Fp) * ldF + (i % Fp)] = v[u];
+            }
         }
-        __syncthreads();
-        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
-        __syncthreads();
-        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = tanhf(v + b2[c]); });
-        __syncthreads();
-        {   // logits, BCE losses and dL/dd: 8 lanes per row   (a2c/algo/gail.py:168-176)
-            const int r = tid >> 3, sub = tid & 7;
+        sg_stage(W, a.params, d.total / 4);
+        SG_PHASE_SYNC(1);
+        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        SG_PHASE_SYNC(2);
+        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        SG_PHASE_SYNC(3);
+        {   // logits, BCE losses and dL/dd: blockDim/32 lanes per row   (a2c/algo/gail.py:168-176)
+            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
             float s = 0.f;
-            for (int c = sub; c < Hp; c += 8) s += H2[r * ldH + c] * w3[c];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            for (int c = sub; c < Hp; c += L) s += H2[r * ldH + c] * w3[c];
+            s = sg_rowlane_sum(s, L);
             if (sub == 0) {
                 const float dd = s + W[d.b3];
                 const bool valid = g * 16 + (r & 15) < a.B;
@@ -115,118 +153,153 @@ __global__ __launch_bounds__(256) void k_disc_grad(DiscArgs a) {
                 LOSS[r] = loss;
             }
         }
-        __syncthreads();
-        // dw3, db3 and dZ2 (in place over H2), one thread per hidden column
+        SG_PHASE_SYNC(4);
+        // dw3, db2, db3 and dZ2 (in place over H2), one thread per hidden column
         for (int c = tid; c < Hp; c += blockDim.x) {
             const float w = w3[c];
-            float gw = 0.f;
+            float gw = 0.f, gb = 0.f;
             for (int r = 0; r < R; ++r) {
                 const float h = H2[r * ldH + c], dd = DD[r];
                 gw += dd * h;
-                H2[r * ldH + c] = dd * w * (1.f - h * h);
+                const float dz = dd * w * (1.f - h * h);
+                gb += dz;
+                H2[r * ldH + c] = dz;
             }
             slab[d.w3 + c] = gw;
+            slab[d.b2 + c] = gb;
         }
-        if (tid < 16) {
+        if (tid >= 256 && tid < 272) {
             float gb = 0.f;
-            if (tid == 0) for (int r = 0; r < R; ++r) gb += DD[r];
-            slab[d.b3 + tid] = gb;
+            if (tid == 256) for (int r = 0; r < R; ++r) gb += DD[r];
+            slab[d.b3 + tid - 256] = gb;
         }
-        if (tid == 64) {
+        if (tid == 320) {
             float le = 0.f, lp = 0.f;
             for (int r = 0; r < 16; ++r) { le += LOSS[r]; lp += LOSS[16 + r]; }
             float* ls = slab + d.total;
             ls[0] = le; ls[1] = lp; ls[2] = 0.f;
         }
-        __syncthreads();
-        sg_grad_tn(H2, ldH, H1, ldH, R, Hp, Hp, slab + d.w2, ldH, false);
-        sg_colsum(H2, ldH, R, Hp, slab + d.b2, false);
-        __syncthreads();
-        sg_layer_nn<2>(H2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
-            const float h = H1[r * ldH + c];
-            H1[r * ldH + c] = v * (1.f - h * h);
+        SG_PHASE_SYNC(5);
+        // dZ1 = (dZ2 W2) * (1 - h1^2) and db1 in the epilogue; dW2 = dZ2^T h1 alongside
+        sg_layer_nn_t<2>(H2, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[2][1]) {
+            const int c = tn * 16 + li;
+            float z[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + 4 * lq + r;
+                    const float h = H1[row * ldH + c];
+                    z[i][r] = acc[i][0][r] * (1.f - h * h);
+                    DZ1[row * ldH + c] = z[i][r];
+                }
+            const float sb = sg_tile_colsum<2>(z);
+            if (lq == 0) slab[d.b1 + c] = sb;
         });
-        __syncthreads();
-        sg_grad_tn(H1, ldH, X, ldF, R, Hp, Fp, slab + d.w1, ldF, false);
-        sg_colsum(H1, ldH, R, Hp, slab + d.b1, false);
+        sg_grad_tn<2>(H2, ldH, H1, ldH, Hp, Hp, slab + d.w2, ldH, false);
+        SG_PHASE_SYNC(6);
+        sg_grad_tn<2>(DZ1, ldH, X, ldF, Hp, Fp, slab + d.w1, ldF, false);
     } else {
         // ------------------------------------------------ mixup group: gradient penalty on 16 rows
         constexpr int R = 16;
         const int g = blockIdx.x - a.G;
         float* XM = buf;
-        float* GX = XM + R * ldF;
+        float* GX = XM + R * ldF;   // g, then gb
         float* H1 = GX + R * ldF;
         float* H2 = H1 + R * ldH;
-        float* D2 = H2 + R * ldH;   // d2, later z2b
-        float* U1 = D2 + R * ldH;   // u1, later sb1
-        float* D1 = U1 + R * ldH;   // d1, later bd2*s2
-        float* BU1 = D1 + R * ldH;  // bu1, later z1b
-        float* ROWL = BU1 + R * ldH;
-        for (int i = tid; i < R * Fp; i += blockDim.x) {
-            const int r = i / Fp, c = i - r * Fp;
-            const int b = g * 16 + r;
-            float v = 0.f;
-            if (b < a.B && c < F) {
-                const float al = a.alpha[b];
-                v = al * a.expert[(size_t)a.eperm[b] * F + c] + (1.f - al) * a.next_feat[(size_t)a.pperm[b] * F + c];
+        float* D2 = H2 + R * ldH;   // d2
+        float* U1 = D2 + R * ldH;   // u1, then sb1, then z1b (all in place, element-wise)
+        float* D1 = U1 + R * ldH;   // d1
+        float* BU1 = D1 + R * ldH;  // bu1
+        float* Z2B = BU1 + R * ldH; // z2b
+        float* ROWL = Z2B + R * ldH;
+        for (int base = tid; base < R * Fp; base += 4 * blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * blockDim.x;
+                const int r = i / Fp, c = i - r * Fp;
+                const int b = g * 16 + r;
+                v[u] = 0.f;
+                if (i < R * Fp && b < a.B && c < F) {
+                    const float al = a.alpha[b];
+                    v[u] = al * a.expert[(size_t)a.eperm[b] * F + c] + (1.f - al) * a.next_feat[(size_t)a.pperm[b] * F + c];
+                }
             }
-            XM[r * ldF + c] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * blockDim.x;
+                if (i < R * Fp) XM[(i / Fp) * ldF + (i % Fp)] = v[u];
+            }
         }
-        __syncthreads();
-        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
-        __syncthreads();
+        sg_stage(W, a.params, d.total / 4);
+        SG_PHASE_SYNC(8);
+        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        SG_PHASE_SYNC(9);
         sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
-            const float h = tanhf(v + b2[c]);
+            const float h = sg_tanh(v + b2[c]);
             H2[r * ldH + c] = h;
             D2[r * ldH + c] = w3[c] * (1.f - h * h);
         });
-        __syncthreads();
-        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+        SG_PHASE_SYNC(10);
+        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {      // u1 = d2 W2
             const float h = H1[r * ldH + c];
             U1[r * ldH + c] = v;
             D1[r * ldH + c] = v * (1.f - h * h);
         });
-        __syncthreads();
-        sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });
-        __syncthreads();
-        {   // per-row |g|, penalty and gb = c_r * g: 16 lanes per row   (a2c/algo/gail.py:88)
-            const int r = tid >> 4, sub = tid & 15;
+        SG_PHASE_SYNC(11);
+        sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });  // g = d1 W1
+        SG_PHASE_SYNC(12);
+        {   // per-row |g|, penalty and gb = c_r * g: blockDim/16 lanes per row   (a2c/algo/gail.py:88)
+            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
             float s = 0.f;
-            for (int c = sub; c < Fp; c += 16) { const float v = GX[r * ldF + c]; s += v * v; }
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            for (int c = sub; c < Fp; c += L) { const float v = GX[r * ldF + c]; s += v * v; }
+            s = sg_rowlane_sum(s, L);
             const float nn = sqrtf(s);
             const bool valid = g * 16 + r < a.B;
             const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
-            for (int c = sub; c < Fp; c += 16) GX[r * ldF + c] *= cr;
+            for (int c = sub; c < Fp; c += L) GX[r * ldF + c] *= cr;
             if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
         }
-        __syncthreads();
-        sg_grad_tn(D1, ldH, GX, ldF, R, Hp, Fp, slab + d.w1, ldF, false);        // dW1  = d1^T gb
-        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {     // bd1 = gb W1^T
+        SG_PHASE_SYNC(13);
+        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {      // bd1 = gb W1^T
             const float h = H1[r * ldH + c];
             BU1[r * ldH + c] = v * (1.f - h * h);
-            U1[r * ldH + c] = v * U1[r * ldH + c];                                 // sb1 = bd1*u1
+            U1[r * ldH + c] = v * U1[r * ldH + c];                                  // sb1 = bd1*u1
         });
-        __syncthreads();
-        sg_grad_tn(D2, ldH, BU1, ldH, R, Hp, Hp, slab + d.w2, ldH, false);       // dW2  = d2^T bu1
-        __syncthreads();
-        sg_layer_nt<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {    // bd2 = bu1 W2^T
-            const float h = H2[r * ldH + c], s2 = 1.f - h * h;
-            D1[r * ldH + c] = v * s2;                                              // -> dw3
-            const float sb2 = v * w3[c];
-            D2[r * ldH + c] = (-2.f * h * sb2) * s2;                               // z2b
+        SG_PHASE_SYNC(14);
+        sg_layer_nt_t<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // bd2 = bu1 W2^T
+            const int c = tn * 16 + li;
+            const float w = w3[c];
+            float t3[1][4], z[1][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float h = H2[row * ldH + c], s2 = 1.f - h * h, v = acc[0][0][r];
+                t3[0][r] = v * s2;                                                  // -> dw3
+                z[0][r] = (-2.f * h * (v * w)) * s2;                                // z2b
+                Z2B[row * ldH + c] = z[0][r];
+            }
+            const float sw = sg_tile_colsum<1>(t3), sb = sg_tile_colsum<1>(z);
+            if (lq == 0) { slab[d.w3 + c] = sw; slab[d.b2 + c] = sb; }
         });
-        __syncthreads();
-        sg_colsum(D1, ldH, R, Hp, slab + d.w3, false);
-        sg_grad_tn(D2, ldH, H1, ldH, R, Hp, Hp, slab + d.w2, ldH, true);         // dW2 += z2b^T h1
-        sg_colsum(D2, ldH, R, Hp, slab + d.b2, false);
-        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {     // h1b = z2b W2
-            const float h = H1[r * ldH + c];
-            BU1[r * ldH + c] = (v - 2.f * h * U1[r * ldH + c]) * (1.f - h * h);    // z1b
+        SG_PHASE_SYNC(15);
+        sg_layer_nn_t<1>(Z2B, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // h1b = z2b W2
+            const int c = tn * 16 + li;
+            float z[1][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float h = H1[row * ldH + c];
+                z[0][r] = (acc[0][0][r] - 2.f * h * U1[row * ldH + c]) * (1.f - h * h);  // z1b
+                U1[row * ldH + c] = z[0][r];
+            }
+            const float sb = sg_tile_colsum<1>(z);
+            if (lq == 0) slab[d.b1 + c] = sb;
         });
-        __syncthreads();
-        sg_grad_tn(BU1, ldH, XM, ldF, R, Hp, Fp, slab + d.w1, ldF, true);        // dW1 += z1b^T x
-        sg_colsum(BU1, ldH, R, Hp, slab + d.b1, false);
+        sg_grad_tn2<1>(D2, ldH, BU1, ldH, Z2B, H1, Hp, Hp, slab + d.w2, ldH, false);   // dW2 = d2^T bu1 + z2b^T h1
+        SG_PHASE_SYNC(16);
+        sg_grad_tn2<1>(D1, ldH, GX, ldF, U1, XM, Hp, Fp, slab + d.w1, ldF, false);     // dW1 = d1^T gb + z1b^T x
         if (tid < 16) slab[d.b3 + tid] = 0.f;
         if (tid == 64) {
             float lg = 0.f;
@@ -235,6 +308,17 @@ __global__ __launch_bounds__(256) void k_disc_grad(DiscArgs a) {
             ls[0] = 0.f; ls[1] = 0.f; ls[2] = lg;
         }
     }
+    SG_PHASE_SYNC(31);
+}
+
+// shape-specialised instances: north-star / Laikago (F 86, Hd 100), Hopper (F 25, Hd 100), the
+// tiny test shape, and the run-time-shape fallback
+static void launch_disc_grad(const SgDiscDesc& dd, dim3 grid, size_t lds, hipStream_t stream, const DiscArgs& a) {
+    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
+    if (kf == 6 && kh == 7) hipLaunchKernelGGL((k_disc_grad<6, 7>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
+    else if (kf == 2 && kh == 7) hipLaunchKernelGGL((k_disc_grad<2, 7>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
+    else if (kf == 1 && kh == 1) hipLaunchKernelGGL((k_disc_grad<1, 1>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((k_disc_grad<0, 0>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
 }
 
 // out[i] = sum over slabs (data-parallel mode: feeds the all-reduce)
@@ -251,18 +335,20 @@ __global__ void k_slab_sum(const float* slabs, int n_slabs, int slab_stride, int
 __global__ __launch_bounds__(256) void k_disc_adam(float* params, float* m, float* v, const float* slabs,
                                                    int n_slabs, int slab_stride, int total, const SgOptState* st,
                                                    float eps, float inv_B, float lambda_, double* loss_acc) {
-    __shared__ float s_step_size, s_bc2_sqrt;
-    if (threadIdx.x == 0) {
-        const double t = (double)st->step;
-        const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-        s_step_size = (float)((double)st->lr / bc1);
-        s_bc2_sqrt = (float)sqrt(bc2);
-    }
-    __syncthreads();
+    const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        float g = 0.f;
-        for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * slab_stride + i];
+        // independent partial sums keep 4 slab loads in flight; combined in a fixed order
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+        int sidx = 0;
+        for (; sidx + 4 <= n_slabs; sidx += 4) {
+            g0 += slabs[(size_t)(sidx + 0) * slab_stride + i];
+            g1 += slabs[(size_t)(sidx + 1) * slab_stride + i];
+            g2 += slabs[(size_t)(sidx + 2) * slab_stride + i];
+            g3 += slabs[(size_t)(sidx + 3) * slab_stride + i];
+        }
+        for (; sidx < n_slabs; ++sidx) g0 += slabs[(size_t)sidx * slab_stride + i];
+        const float g = (g0 + g1) + (g2 + g3);
         float mi = m[i], vi = v[i];
         mi = mi + (g - mi) * (float)(1.0 - 0.9);
         vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
@@ -271,16 +357,19 @@ __global__ __launch_bounds__(256) void k_disc_adam(float* params, float* m, floa
         m[i] = mi;
         v[i] = vi;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {  // last block has the fewest parameters
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int s = 0; s < n_slabs; ++s) {
+        for (int s = threadIdx.x; s < n_slabs; s += 64) {
             const float* ls = slabs + (size_t)s * slab_stride + total;
             s0 += ls[0]; s1 += ls[1]; s2 += ls[2];
         }
-        const float el = s0 * inv_B, pl = s1 * inv_B, gp = lambda_ * (s2 * inv_B);
-        loss_acc[0] += (double)(el + pl + gp);
-        loss_acc[1] += (double)el;
-        loss_acc[2] += (double)pl;
+        s0 = sg_wave_sum(s0); s1 = sg_wave_sum(s1); s2 = sg_wave_sum(s2);
+        if (threadIdx.x == 0) {
+            const float el = s0 * inv_B, pl = s1 * inv_B, gp = lambda_ * (s2 * inv_B);
+            loss_acc[0] += (double)(el + pl + gp);
+            loss_acc[1] += (double)el;
+            loss_acc[2] += (double)pl;
+        }
     }
 }
 
@@ -324,9 +413,9 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
             X[r * ldF + c] = (base + r < a.n && c < d.F) ? a.x[(size_t)(base + r) * d.F + c] : 0.f;
         }
         __syncthreads();
-        sg_layer_nt<2>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
+        sg_layer_nt<2>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         __syncthreads();
-        sg_layer_nt<2>(H1, ldH, W + d.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = tanhf(v + b2[c]); });
+        sg_layer_nt<2>(H1, ldH, W + d.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
         const int r = tid >> 3, sub = tid & 7;
         float s = 0.f;
@@ -570,6 +659,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     a.next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
     a.B = B_loc; a.G = G; a.inv_B = 1.0f / (float)batch_size; a.lambda_ = 10.0f;
     a.slabs = d->d_slabs; a.slab_stride = slab_stride; a.st = reinterpret_cast<SgOptState*>(d->d_state);
+    a.dbg = d->d_dbg;
     const size_t lds = disc_grad_lds_bytes(dd);
     const int nblk = (dd.total + 255) / 256;
     float* grad = d->d_slabs + (size_t)(2 * G) * slab_stride;   // data-parallel: reduced gradient "slab"
@@ -579,7 +669,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
         a.alpha = d->d_alpha + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
         a.pperm = d->d_pperm + (size_t)k * B_loc;
         sg_prof_begin(ctx, SG_PROF_DISC_GRAD);
-        hipLaunchKernelGGL(k_disc_grad, dim3(2 * G), dim3(256), lds, ctx->stream, a);
+        launch_disc_grad(dd, dim3(2 * G), lds, ctx->stream, a);
         sg_prof_end(ctx, SG_PROF_DISC_GRAD);
         if (world > 1) {
             hipLaunchKernelGGL(k_slab_sum, dim3((slab_stride + 255) / 256), dim3(256), 0, ctx->stream, d->d_slabs, 2 * G,
@@ -709,5 +799,21 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipMemcpyAsync(rms_state, rms, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Test hook: enable/read per-phase shader-clock timestamps of k_disc_grad (tools/phase_times.py).
+extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, int n_blocks) {
+    SG_REQUIRE(d, "sg_test_disc_phase_times: NULL argument");
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    if (enable && !d->d_dbg) {
+        SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 64));
+        SG_CHECK(hipMemset(d->d_dbg, 0, sizeof(long long) * 32 * 64));
+    }
+    if (out && d->d_dbg) {
+        SG_REQUIRE(n_blocks <= 64, "sg_test_disc_phase_times: at most 64 blocks");
+        SG_CHECK(hipMemcpy(out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));
+    }
+    if (!enable && d->d_dbg) { SG_CHECK(hipFree(d->d_dbg)); d->d_dbg = nullptr; }
     return 0;
 }

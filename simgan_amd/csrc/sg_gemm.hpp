@@ -17,8 +17,15 @@
 // does not care about the order of its terms, each routine assigns reduction indices to (q, step)
 // in whatever order makes the LDS reads wide -- the SAME assignment for the A and the B operand:
 //        NT:  k = 8c + 2q + s   (s = 0,1)        NN, TN:  k = 16c + 4q + s   (s = 0..3)
-// The result is exact fp32 (each MFMA is a k-ordered fmaf chain), only the summation order differs
-// from a scalar loop.
+// (all K extents are multiples of 16).  The result is exact fp32 (each MFMA is a k-ordered fmaf
+// chain), only the summation order differs from a scalar loop.
+//
+// Latency structure: these GEMMs are short (K <= 128, a handful of tiles per wave), so instead of
+// a software-pipelined K loop each routine issues ALL LDS reads of a K block (up to 8 chunks of
+// 16) first and then streams the MFMAs behind them -- one LDS latency per GEMM instead of one per
+// K step.  K/16 is a runtime value dispatched to compile-time-unrolled bodies.  A lone 16x16 tile
+// (MT*NT == 1) alternates between two accumulators so consecutive MFMAs never wait on the
+// 40-cycle dependent-accumulator latency.
 //
 // C/D fragment of the 16x16 tile: acc[r] holds row 4*(lane>>4) + r, column lane&15.
 #pragma once
@@ -33,6 +40,29 @@ __device__ __forceinline__ f32x4 sg_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 8-byte LDS read that stays a ds_read_b64.  Left alone, the compiler fuses two of them into
+// ds_read2_b64, which is banked modulo 32 dwords in 16-lane groups (2-way conflict on the
+// ld == 4 (mod 8) layout, and half the bytes per clock); ds_read_b64 is banked modulo 64 in
+// 32-lane groups and is conflict-free on it.  volatile forbids the fusion; the compiler still
+// tracks the read in its lgkmcnt bookkeeping.
+__device__ __forceinline__ float2 sg_lds_read_b64(const float* p) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef const volatile v2f __attribute__((address_space(3))) * lds_v2f_ptr;  // explicit LDS pointer:
+    const v2f v = *(lds_v2f_ptr)(p);  // a volatile generic pointer would become flat_load
+    return float2{v.x, v.y};
+}
+
+// tanh for activations: 1 - 2/(exp(2x)+1) on the fast exp/rcp units, with the odd Taylor
+// polynomial below |x| = 0.1 where that form would cancel.  Absolute error < 2e-7 (fp32 round-off
+// class), far inside the 1e-4 parity budget; ~4x cheaper than the libm call in the epilogues.
+__device__ __forceinline__ float sg_tanh(float x) {
+    const float x2 = x * x;
+    const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+    const float t = __expf(2.f * x);
+    const float big = 1.f - 2.f * __frcp_rn(t + 1.f);
+    return fabsf(x) < 0.1f ? poly : big;
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void sg_acc_zero(f32x4 (&acc)[MT][NT]) {
 #pragma unroll
@@ -41,80 +71,158 @@ __device__ __forceinline__ void sg_acc_zero(f32x4 (&acc)[MT][NT]) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// C[m][n] += sum_k A[m][k] * B[n][k].   A -> row m0 of [.][lda], B -> row n0 of [.][ldb]; K % 8 == 0.
+// Dispatch a runtime chunk count (K/16) to bodies unrolled for 1..8 chunks.
+#define SG_KC_DISPATCH(kc, BODY)                                   \
+    do {                                                           \
+        int _kc = (kc);                                            \
+        while (_kc > 8) { BODY(8); _kc -= 8; }                     \
+        switch (_kc) {                                             \
+            case 8: BODY(8); break; case 7: BODY(7); break;        \
+            case 6: BODY(6); break; case 5: BODY(5); break;        \
+            case 4: BODY(4); break; case 3: BODY(3); break;        \
+            case 2: BODY(2); break; case 1: BODY(1); break;        \
+            default: break;                                        \
+        }                                                          \
+    } while (0)
+
+// ---- NT:  C[m][n] += sum_k A[m][k] * B[n][k].  A -> row m0 of [.][lda], B -> row n0 of [.][ldb].
 // (activations x weight^T: nn.Linear forward; also g x W1^T in the gradient-penalty backward)
+template <int MT, int NT, int KC>
+__device__ __forceinline__ void sg_mma_nt_blk(const float*& ap, int lda, const float*& bp, int ldb,
+                                              f32x4 (&acc)[MT][NT], f32x4& alt) {
+    constexpr bool DUAL = (MT * NT == 1);
+    float2 a[KC][2][MT], b[KC][2][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[c][h][i] = sg_lds_read_b64(ap + i * 16 * lda + 16 * c + 8 * h);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[c][h][j] = sg_lds_read_b64(bp + j * 16 * ldb + 16 * c + 8 * h);
+        }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = sg_mfma(a[c][h][i].x, b[c][h][j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (DUAL) alt = sg_mfma(a[c][h][i].y, b[c][h][j].y, alt);
+                    else acc[i][j] = sg_mfma(a[c][h][i].y, b[c][h][j].y, acc[i][j]);
+                }
+        }
+    ap += 16 * KC;
+    bp += 16 * KC;
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void sg_mma_nt(const float* A, int lda, const float* B, int ldb, int K,
                                           f32x4 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     const float* ap = A + li * lda + 2 * lq;
     const float* bp = B + li * ldb + 2 * lq;
-    for (int k = 0; k < K; k += 8) {
-        float2 a[MT], b[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float2*>(ap + i * 16 * lda + k);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float2*>(bp + j * 16 * ldb + k);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = sg_mfma(a[i].x, b[j].x, acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = sg_mfma(a[i].y, b[j].y, acc[i][j]);
-    }
+    f32x4 alt = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SG_BODY(N) sg_mma_nt_blk<MT, NT, N>(ap, lda, bp, ldb, acc, alt)
+    SG_KC_DISPATCH(K >> 4, SG_BODY);
+#undef SG_BODY
+    if (MT * NT == 1) acc[0][0] += alt;
 }
 
-// C[m][n] += sum_k A[m][k] * B[k][n].   A -> row m0 of [.][lda]; B -> column n0 of [K][ldb]; K % 16 == 0.
+// ---- NN:  C[m][n] += sum_k A[m][k] * B[k][n].  A -> row m0 of [.][lda]; B -> column n0 of [K][ldb].
 // (dY x W: back-propagation through nn.Linear to its input)
+template <int MT, int NT, int KC>
+__device__ __forceinline__ void sg_mma_nn_blk(const float*& ap, int lda, const float*& bp, int ldb,
+                                              f32x4 (&acc)[MT][NT], f32x4& alt) {
+    constexpr bool DUAL = (MT * NT == 1);
+    float4 a[KC][MT];
+    float b[KC][4][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[c][i] = *reinterpret_cast<const float4*>(ap + i * 16 * lda + 16 * c);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[c][s][j] = bp[(16 * c + s) * ldb + j * 16];
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float av = s == 0 ? a[c][i].x : s == 1 ? a[c][i].y : s == 2 ? a[c][i].z : a[c][i].w;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (DUAL && (s & 1)) alt = sg_mfma(av, b[c][s][j], alt);
+                    else acc[i][j] = sg_mfma(av, b[c][s][j], acc[i][j]);
+                }
+            }
+    ap += 16 * KC;
+    bp += 16 * KC * ldb;
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void sg_mma_nn(const float* A, int lda, const float* B, int ldb, int K,
                                           f32x4 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     const float* ap = A + li * lda + 4 * lq;
     const float* bp = B + (4 * lq) * ldb + li;
-    for (int k = 0; k < K; k += 16) {
-        float4 a[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(ap + i * 16 * lda + k);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float b[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = bp[(k + s) * ldb + j * 16];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = sg_mfma(av, b[j], acc[i][j]);
-            }
-        }
-    }
+    f32x4 alt = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SG_BODY(N) sg_mma_nn_blk<MT, NT, N>(ap, lda, bp, ldb, acc, alt)
+    SG_KC_DISPATCH(K >> 4, SG_BODY);
+#undef SG_BODY
+    if (MT * NT == 1) acc[0][0] += alt;
 }
 
-// C[m][n] += sum_r A[r][m] * B[r][n].   A -> column m0 of [K][lda]; B -> column n0 of [K][ldb]; K % 16 == 0.
+// ---- TN:  C[m][n] += sum_r A[r][m] * B[r][n].  A -> column m0 of [K][lda]; B -> column n0 of [K][ldb].
 // (dW = dY^T X: the weight-gradient reduction over the rows of a tile)
+template <int MT, int NT, int KC>
+__device__ __forceinline__ void sg_mma_tn_blk(const float*& ap, int lda, const float*& bp, int ldb,
+                                              f32x4 (&acc)[MT][NT], f32x4& alt) {
+    constexpr bool DUAL = (MT * NT == 1);
+    float a[KC][4][MT], b[KC][4][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[c][s][i] = ap[(16 * c + s) * lda + i * 16];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[c][s][j] = bp[(16 * c + s) * ldb + j * 16];
+        }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (DUAL && (s & 1)) alt = sg_mfma(a[c][s][i], b[c][s][j], alt);
+                    else acc[i][j] = sg_mfma(a[c][s][i], b[c][s][j], acc[i][j]);
+                }
+    ap += 16 * KC * lda;
+    bp += 16 * KC * ldb;
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void sg_mma_tn(const float* A, int lda, const float* B, int ldb, int K,
                                           f32x4 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     const float* ap = A + (4 * lq) * lda + li;
     const float* bp = B + (4 * lq) * ldb + li;
-    for (int k = 0; k < K; k += 16) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float a[MT], b[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = ap[(k + s) * lda + i * 16];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = bp[(k + s) * ldb + j * 16];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = sg_mfma(a[i], b[j], acc[i][j]);
-        }
-    }
+    f32x4 alt = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SG_BODY(N) sg_mma_tn_blk<MT, NT, N>(ap, lda, bp, ldb, acc, alt)
+    SG_KC_DISPATCH(K >> 4, SG_BODY);
+#undef SG_BODY
+    if (MT * NT == 1) acc[0][0] += alt;
 }
 
 // Visit the 4 accumulator elements this lane owns in the tile whose top-left is (row0, col0).
@@ -125,71 +233,145 @@ __device__ __forceinline__ void sg_tile_foreach(const f32x4& acc, int row0, int 
     for (int r = 0; r < 4; ++r) f(row0 + 4 * lq + r, col0 + li, acc[r]);
 }
 
+// Column sum over all 16*MT rows of a column block: v[i][r] are this lane's (post-epilogue) values
+// of row tile i, register r.  Every lane returns the total of column (lane & 15).
+template <int MT>
+__device__ __forceinline__ float sg_tile_colsum(const float (&v)[MT][4]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup-level layer routines.  All waves of the workgroup call them; column tiles of the
 // output are dealt round-robin to waves.  R = 16*MT rows are processed per call.
+// The *_t variants hand the epilogue a whole column block: ep(tn, acc[MT][1]).
 // ---------------------------------------------------------------------------------------------
 
-// out[r][c] = ep(r, c, sum_k in[r][k] * W[c][k])  for c < Np   (forward layer / "NT")
 template <int MT, typename EP>
-__device__ __forceinline__ void sg_layer_nt(const float* in, int ldi, const float* W, int ldw,
-                                            int K, int Np, EP&& ep) {
+__device__ __forceinline__ void sg_layer_nt_t(const float* in, int ldi, const float* W, int ldw,
+                                              int K, int Np, EP&& ep) {
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int tn = wave; tn * 16 < Np; tn += nw) {
         f32x4 acc[MT][1];
         sg_acc_zero(acc);
         sg_mma_nt<MT, 1>(in, ldi, W + tn * 16 * ldw, ldw, K, acc);
+        ep(tn, acc);
+    }
+}
+
+template <int MT, typename EP>
+__device__ __forceinline__ void sg_layer_nn_t(const float* dY, int ldy, const float* W, int ldw,
+                                              int K, int Np, EP&& ep) {
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int tn = wave; tn * 16 < Np; tn += nw) {
+        f32x4 acc[MT][1];
+        sg_acc_zero(acc);
+        sg_mma_nn<MT, 1>(dY, ldy, W + tn * 16, ldw, K, acc);
+        ep(tn, acc);
+    }
+}
+
+// out[r][c] = ep(r, c, sum_k in[r][k] * W[c][k])  for c < Np   (forward layer / "NT")
+template <int MT, typename EP>
+__device__ __forceinline__ void sg_layer_nt(const float* in, int ldi, const float* W, int ldw,
+                                            int K, int Np, EP&& ep) {
+    sg_layer_nt_t<MT>(in, ldi, W, ldw, K, Np, [&](int tn, f32x4 (&acc)[MT][1]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) sg_tile_foreach(acc[i][0], i * 16, tn * 16, ep);
-    }
+    });
 }
 
 // out[r][c] = ep(r, c, sum_k dY[r][k] * W[k][c])  for c < Np   (backward to the layer input / "NN")
 template <int MT, typename EP>
 __device__ __forceinline__ void sg_layer_nn(const float* dY, int ldy, const float* W, int ldw,
                                             int K, int Np, EP&& ep) {
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int tn = wave; tn * 16 < Np; tn += nw) {
-        f32x4 acc[MT][1];
-        sg_acc_zero(acc);
-        sg_mma_nn<MT, 1>(dY, ldy, W + tn * 16, ldw, K, acc);
+    sg_layer_nn_t<MT>(dY, ldy, W, ldw, K, Np, [&](int tn, f32x4 (&acc)[MT][1]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) sg_tile_foreach(acc[i][0], i * 16, tn * 16, ep);
+    });
+}
+
+// ---- weight gradient ("TN"):  G[m][n] (+)= sum_{r<R} dY[r][m] X[r][n]  (+ sum_r dY2[r][m] X2[r][n])
+// written to global memory.  Each wave owns whole 16-row panels of G: it reads its A fragment
+// (16 columns of dY) once, all B fragments of up to 8 column tiles, issues every LDS read before
+// the first MFMA, accumulates both contributions in registers and stores the panel once.  The
+// optional second operand pair lets a gradient with two terms (e.g. dW2 = d2^T bu1 + z2b^T h1 in
+// the gradient penalty) be formed without a read-modify-write of G.   R = 16*KC rows.
+template <int KC, int NTN, bool TWO>
+__device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, int lda, const float* bp,
+                                            const float* bp2, int ldb, float* G, int ldg, bool accumulate) {
+    float a[TWO ? 2 : 1][KC][4], b[TWO ? 2 : 1][KC][4][NTN];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a[0][c][s] = ap[(16 * c + s) * lda];
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) b[0][c][s][j] = bp[(16 * c + s) * ldb + 16 * j];
+            if (TWO) {
+                a[TWO ? 1 : 0][c][s] = ap2[(16 * c + s) * lda];
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) b[TWO ? 1 : 0][c][s][j] = bp2[(16 * c + s) * ldb + 16 * j];
+            }
+        }
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int src = 0; src < (TWO ? 2 : 1); ++src)
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) acc[j] = sg_mfma(a[src][c][s], b[src][c][s][j], acc[j]);
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* p = G + (4 * lq + r) * ldg + 16 * j + li;
+            *p = accumulate ? *p + acc[j][r] : acc[j][r];
+        }
+}
+
+template <int KC>
+__device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const float* X, int ldx,
+                                            const float* dY2, const float* X2, int Mp, int Np,
+                                            float* G, int ldg, bool accumulate) {
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const int tm_n = Mp >> 4, tn_n = Np >> 4, blocks_n = (tn_n + 7) >> 3;
+    for (int t = wave; t < tm_n * blocks_n; t += nw) {
+        const int tm = t / blocks_n, tb = t % blocks_n;
+        const int ntn = tn_n - 8 * tb < 8 ? tn_n - 8 * tb : 8;
+        const float* ap = dY + (4 * lq) * ldy + tm * 16 + li;
+        const float* bp = X + (4 * lq) * ldx + tb * 128 + li;
+        const float* ap2 = dY2 ? dY2 + (4 * lq) * ldy + tm * 16 + li : ap;
+        const float* bp2 = X2 ? X2 + (4 * lq) * ldx + tb * 128 + li : bp;
+        float* g = G + (size_t)(tm * 16) * ldg + tb * 128;
+#define SG_PANEL(N)                                                                              \
+    do {                                                                                         \
+        if (dY2) sg_tn_panel<KC, N, true>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);       \
+        else sg_tn_panel<KC, N, false>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);          \
+    } while (0)
+        switch (ntn) {
+            case 8: SG_PANEL(8); break; case 7: SG_PANEL(7); break; case 6: SG_PANEL(6); break;
+            case 5: SG_PANEL(5); break; case 4: SG_PANEL(4); break; case 3: SG_PANEL(3); break;
+            case 2: SG_PANEL(2); break; case 1: SG_PANEL(1); break; default: break;
+        }
+#undef SG_PANEL
     }
 }
 
-// G[m][n] (+)= sum_{r<R} dY[r][m] * X[r][n]  for m < Mp, n < Np, written to global memory
-// (weight gradient / "TN").  Tiles are dealt to waves in pairs along n to share the A fragment.
-__device__ __forceinline__ void sg_grad_tn(const float* dY, int ldy, const float* X, int ldx, int R,
-                                           int Mp, int Np, float* G, int ldg, bool accumulate) {
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int tm_n = Mp >> 4, tn_n = Np >> 4, pairs_n = (tn_n + 1) >> 1;
-    for (int t = wave; t < tm_n * pairs_n; t += nw) {
-        const int tm = t / pairs_n, tp = t % pairs_n;
-        const int tn0 = tp * 2, tn1 = (tn0 + 1 < tn_n) ? tn0 + 1 : tn0;  // odd tail: redo tn0, skip store
-        f32x4 acc[1][2];
-        sg_acc_zero(acc);
-        {
-            const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-            const float* ap = dY + (4 * lq) * ldy + tm * 16 + li;
-            const float* b0 = X + (4 * lq) * ldx + tn0 * 16 + li;
-            const float* b1 = X + (4 * lq) * ldx + tn1 * 16 + li;
-            for (int k = 0; k < R; k += 16) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float a = ap[(k + s) * ldy];
-                    acc[0][0] = sg_mfma(a, b0[(k + s) * ldx], acc[0][0]);
-                    acc[0][1] = sg_mfma(a, b1[(k + s) * ldx], acc[0][1]);
-                }
-            }
-        }
-        auto st = [&](int r, int c, float v) {
-            float* p = G + r * ldg + c;
-            *p = accumulate ? *p + v : v;
-        };
-        sg_tile_foreach(acc[0][0], tm * 16, tn0 * 16, st);
-        if (tn1 != tn0) sg_tile_foreach(acc[0][1], tm * 16, tn1 * 16, st);
-    }
+template <int KC>
+__device__ __forceinline__ void sg_grad_tn(const float* dY, int ldy, const float* X, int ldx, int Mp,
+                                           int Np, float* G, int ldg, bool accumulate) {
+    sg_grad_tn2<KC>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
 }
 
 // g[c] (+)= sum_{r<R} M[r][c]  for c < Np  (bias gradients), one thread per column.
@@ -202,11 +384,26 @@ __device__ __forceinline__ void sg_colsum(const float* M, int ldm, int R, int Np
     }
 }
 
-// Linear copy global -> LDS, 16 bytes per lane (n4 = number of float4).
+// Linear copy global -> LDS, 16 bytes per lane (n4 = number of float4), 8 loads in flight per
+// lane per round (all rounds when n4 is a compile-time constant and the loop unrolls).
 __device__ __forceinline__ void sg_stage(float* lds, const float* __restrict__ g, int n4) {
     const float4* src = reinterpret_cast<const float4*>(g);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    const int nt = blockDim.x;
+#pragma unroll 2
+    for (int base = threadIdx.x; base < n4; base += 8 * nt) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nt;
+            v[u] = i < n4 ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nt;
+            if (i < n4) dst[i] = v[u];
+        }
+    }
 }
 
 __device__ __forceinline__ float sg_wave_sum(float v) {

@@ -49,10 +49,10 @@ __device__ __forceinline__ void trunk_forward(const SgPolicyDesc& d, const SgTru
     const float* b2 = W + tr.b2;
     const float* bh = W + tr.bh;
     sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp,
-                    [&](int r, int c, float v) { H1[r * ldH + c] = tanhf(v + b1[c]); });
+                    [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
     __syncthreads();
     sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp,
-                    [&](int r, int c, float v) { H2[r * ldH + c] = tanhf(v + b2[c]); });
+                    [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
     __syncthreads();
     sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp,
                     [&](int r, int c, float v) { OUT[r * ldP + c] = v + bh[c]; });
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
             float* h2 = H2[ti];
             float* dout = OUT[ti];
             // head weight / bias gradients
-            sg_grad_tn(dout, ldP, h2, ldH, R, tr.Pp, d.Hp, g + tr.wh, ldH, accumulate);
+            sg_grad_tn<MT>(dout, ldP, h2, ldH, tr.Pp, d.Hp, g + tr.wh, ldH, accumulate);
             sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, accumulate);
             if (tr.EX) sg_colsum(OUT[1], ldP, R, SG_PAD16(tr.EX), g + tr.ex, accumulate);
             __syncthreads();
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
                 h2[r * ldH + c] = v * (1.f - h * h);
             });
             __syncthreads();
-            sg_grad_tn(h2, ldH, h1, ldH, R, d.Hp, d.Hp, g + tr.w2, ldH, accumulate);
+            sg_grad_tn<MT>(h2, ldH, h1, ldH, d.Hp, d.Hp, g + tr.w2, ldH, accumulate);
             sg_colsum(h2, ldH, R, d.Hp, g + tr.b2, accumulate);
             __syncthreads();
             // dZ1 = (dZ2 W2) * (1 - h1^2), in place over h1
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
                 h1[r * ldH + c] = v * (1.f - h * h);
             });
             __syncthreads();
-            sg_grad_tn(h1, ldH, X, ldO, R, d.Hp, d.Op, g + tr.w1, ldO, accumulate);
+            sg_grad_tn<MT>(h1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, accumulate);
             sg_colsum(h1, ldH, R, d.Hp, g + tr.b1, accumulate);
             __syncthreads();
         }
@@ -553,7 +553,15 @@ __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_sl
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float g = 0.f;
     if (i < total + 8) {
-        for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * slab_stride + i];
+        // 8 independent partial sums keep 8 slab loads in flight; combined in a fixed order
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= n_slabs; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(s + u) * slab_stride + i];
+        }
+        for (; s < n_slabs; ++s) p[0] += slabs[(size_t)s * slab_stride + i];
+        g = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         grad[i] = g;
     }
     float sq = (i < total) ? g * g : 0.f;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_sl
     __syncthreads();
     if (threadIdx.x == 0) {
         part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-        if (blockIdx.x == 0) st->step += 1.0f;
+        if (blockIdx.x == 0) sg_opt_advance(st);
     }
 }
 
@@ -583,7 +591,8 @@ __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float
                                                   const float* part, int n_part, int total,
                                                   const SgOptState* st, float eps, float max_norm,
                                                   float inv_mb, double* loss_acc) {
-    __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+    __shared__ float s_coef;
+    const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
     if (threadIdx.x < 64) {
         float s = 0.f;
         for (int j = threadIdx.x; j < n_part; j += 64) s += part[j];
@@ -592,10 +601,6 @@ __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float
             const float norm = sqrtf(s);
             float coef = max_norm / (norm + 1e-6f);
             s_coef = coef > 1.f ? 1.f : coef;
-            const double t = (double)st->step;
-            const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-            s_step_size = (float)((double)st->lr / bc1);
-            s_bc2_sqrt = (float)sqrt(bc2);
         }
     }
     __syncthreads();

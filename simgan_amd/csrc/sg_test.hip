@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void k_gemm_test(GemmTestArgs a) {
     else if (a.mode == 1)
         sg_layer_nn<MT>(As, lda, Bs, ldb, a.K, a.N, [&](int r, int c, float v) { Cs[r * ldc + c] = v; });
     else {
-        sg_grad_tn(As, lda, Bs, ldb, a.K, a.M, a.N, a.C, a.N, false);
-        sg_grad_tn(As, lda, Bs, ldb, a.K, a.M, a.N, a.C, a.N, true);   // exercises the accumulate path: C = 2*A^T B
+        // TN: K (= tile rows R) is a compile-time chunk count in the product kernels
+        if (a.K == 16) { sg_grad_tn<1>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, false); sg_grad_tn<1>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, true); }
+        else if (a.K == 32) { sg_grad_tn<2>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, false); sg_grad_tn<2>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, true); }
+        else { sg_grad_tn<4>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, false); sg_grad_tn<4>(As, lda, Bs, ldb, a.M, a.N, a.C, a.N, true); }   // exercises the accumulate path: C = 2*A^T B
         return;
     }
     __syncthreads();
@@ -59,5 +61,67 @@ extern "C" int sg_test_gemm(sg_ctx* ctx, int mode, int M, int N, int K, const fl
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     SG_CHECK(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Engine micro-benchmark (tools/gemm_bench.py): one workgroup repeats a layer GEMM on LDS-resident
+// operands `iters` times (barrier between repetitions, like a real phase) and reports shader clocks.
+struct GemmBenchArgs {
+    int mode, K, Np, iters, epi;
+    long long* out;
+    float* sink;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512) void k_gemm_bench(GemmBenchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 16 * MT;
+    const int ldk = SG_LD(a.K), ldn = SG_LD(a.Np);
+    // NT: in [R][ldk], W [Np][ldk];  NN: in [R][ldk], W [K][ldn];  TN: dY [R][ldk'] ...
+    float* In = smem;
+    float* Wt = In + R * (ldk > ldn ? ldk : ldn);
+    float* Out = Wt + (a.K > a.Np ? a.K : a.Np) * (ldk > ldn ? ldk : ldn);
+    const int total = R * (ldk > ldn ? ldk : ldn) + (a.K > a.Np ? a.K : a.Np) * (ldk > ldn ? ldk : ldn) + R * ldn;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) smem[i] = 0.001f * (float)((i * 7) % 13);
+    __syncthreads();
+    const long long t0 = clock64();
+    for (int it = 0; it < a.iters; ++it) {
+        if (a.mode == 0) {
+            if (a.epi)
+                sg_layer_nt<MT>(In, ldk, Wt, ldk, a.K, a.Np, [&](int r, int c, float v) { Out[r * ldn + c] = sg_tanh(v); });
+            else
+                sg_layer_nt<MT>(In, ldk, Wt, ldk, a.K, a.Np, [&](int r, int c, float v) { Out[r * ldn + c] = v; });
+        } else if (a.mode == 1) {
+            sg_layer_nn<MT>(In, ldk, Wt, ldn, a.K, a.Np, [&](int r, int c, float v) { Out[r * ldn + c] = v; });
+        } else {
+            sg_grad_tn<MT>(In, ldk, Out, ldn, a.K, a.Np, a.sink, a.Np, false);
+        }
+        __syncthreads();
+    }
+    const long long t1 = clock64();
+    if (threadIdx.x == 0) a.out[0] = t1 - t0;
+    if (a.sink && threadIdx.x == 0) a.sink[0] = Out[0];
+}
+
+extern "C" int sg_test_gemm_bench(sg_ctx* ctx, int mode, int MT, int K, int Np, int threads, int iters, int epi,
+                                  long long* cycles) {
+    SG_REQUIRE(ctx && cycles, "sg_test_gemm_bench: NULL argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int R = 16 * MT, ldk = SG_LD(K), ldn = SG_LD(Np), ldm = ldk > ldn ? ldk : ldn, big = K > Np ? K : Np;
+    const size_t lds = sizeof(float) * ((size_t)R * ldm + (size_t)big * ldm + (size_t)R * ldn);
+    SG_REQUIRE(lds <= (size_t)ctx->lds_bytes, "sg_test_gemm_bench: LDS %zu > %d", lds, ctx->lds_bytes);
+    long long* d_out;
+    float* d_sink;
+    SG_CHECK(hipMalloc((void**)&d_out, 64));
+    SG_CHECK(hipMalloc((void**)&d_sink, sizeof(float) * (size_t)(K > 16 ? K : 16) * (Np > 16 ? Np : 16)));
+    GemmBenchArgs a{mode, K, Np, iters, epi, d_out, d_sink};
+    if (MT == 4) hipLaunchKernelGGL(k_gemm_bench<4>, dim3(1), dim3(threads), lds, ctx->stream, a);
+    else if (MT == 2) hipLaunchKernelGGL(k_gemm_bench<2>, dim3(1), dim3(threads), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(k_gemm_bench<1>, dim3(1), dim3(threads), lds, ctx->stream, a);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_CHECK(hipMemcpy(cycles, d_out, sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_out); (void)hipFree(d_sink);
     return 0;
 }
