@@ -170,25 +170,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from simgan_amd.dist import ProcessGroup
+    pg = ProcessGroup()
+    rank, world = pg.rank, pg.world
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run "
+                         "(one process per GPU)")
 
     import simgan_amd as sg
     from simgan_amd import _lib
     ctx = _lib.Context.default()   # device = LOCAL_RANK
     lib = ctx.lib
-    if world > 1:
-        ids = [_lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], rank, world)
+    pg.init_device_comm(ctx, _lib.comm_unique_id)
 
     w = WORKLOADS[args.workload]
     pol, disc, agent, ro, loader, expert = build_problem(sg, w, seed=0)
@@ -197,8 +190,7 @@ def main():
 
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+        pg.barrier()
 
     for _ in range(args.warmup):
         one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
@@ -210,11 +202,7 @@ def main():
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = pg.max(elapsed)
 
     # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
     ctx.profile_reset()
@@ -260,9 +248,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, expert, args.cpu_seconds)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    pg.shutdown()
 
 
 if __name__ == "__main__":

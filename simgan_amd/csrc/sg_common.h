@@ -95,6 +95,7 @@ struct sg_ctx {
     std::vector<hipEvent_t> event_pool;
     SgComm* comm = nullptr;
     int rank = 0, world = 1;
+    bool use_comm = false;        // issue the data-parallel collectives (world > 1, or forced for a 1-rank self-test)
     // scratch
     float* d_scratch = nullptr;   // generic device scratch (host<->device staging for API calls)
     size_t scratch_bytes = 0;

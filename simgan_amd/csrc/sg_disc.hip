@@ -98,7 +98,6 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_grad(DiscArgs a) {
     const float* w3 = W + d.w3;
     float* buf = W + d.total;
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    if (blockIdx.x == 0 && tid == 0) sg_opt_advance(a.st);  // Adam t for the k_disc_adam that follows
     if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
 
     const int li = tid & 15, lq = (tid & 63) >> 4;
@@ -132,6 +131,9 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_grad(DiscArgs a) {
         }
         sg_stage(W, a.params, d.total / 4);
         SG_PHASE_SYNC(1);
+        // Adam t / bias corrections for the k_disc_adam that follows: one lane of the last wave, which
+        // has no tile in the 7-tile GEMM phases, so the double-precision pow() hides behind them
+        if (blockIdx.x == 0 && tid == (int)blockDim.x - 64) sg_opt_advance(a.st);
         sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         SG_PHASE_SYNC(2);
         sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
@@ -338,22 +340,21 @@ __global__ __launch_bounds__(256) void k_disc_adam(float* params, float* m, floa
     const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        // independent partial sums keep 4 slab loads in flight; combined in a fixed order
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-        int sidx = 0;
-        for (; sidx + 4 <= n_slabs; sidx += 4) {
-            g0 += slabs[(size_t)(sidx + 0) * slab_stride + i];
-            g1 += slabs[(size_t)(sidx + 1) * slab_stride + i];
-            g2 += slabs[(size_t)(sidx + 2) * slab_stride + i];
-            g3 += slabs[(size_t)(sidx + 3) * slab_stride + i];
+        // 16 slab loads in flight per lane (one memory round trip for the usual 2*128/16 slabs);
+        // partial sums are combined in a fixed order, so the result is deterministic
+        float mi = m[i], vi = v[i], pi = params[i];
+        float g = 0.f;
+        for (int s0 = 0; s0 < n_slabs; s0 += 16) {
+            float p[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[u] = (s0 + u < n_slabs) ? slabs[(size_t)(s0 + u) * slab_stride + i] : 0.f;
+            g += (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) +
+                 (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
         }
-        for (; sidx < n_slabs; ++sidx) g0 += slabs[(size_t)sidx * slab_stride + i];
-        const float g = (g0 + g1) + (g2 + g3);
-        float mi = m[i], vi = v[i];
         mi = mi + (g - mi) * (float)(1.0 - 0.9);
         vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
         const float denom = sqrtf(vi) / s_bc2_sqrt + eps;
-        params[i] = params[i] - s_step_size * (mi / denom);
+        params[i] = pi - s_step_size * (mi / denom);
         m[i] = mi;
         v[i] = vi;
     }
@@ -671,14 +672,14 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
         sg_prof_begin(ctx, SG_PROF_DISC_GRAD);
         launch_disc_grad(dd, dim3(2 * G), lds, ctx->stream, a);
         sg_prof_end(ctx, SG_PROF_DISC_GRAD);
-        if (world > 1) {
+        if (ctx->use_comm) {
             hipLaunchKernelGGL(k_slab_sum, dim3((slab_stride + 255) / 256), dim3(256), 0, ctx->stream, d->d_slabs, 2 * G,
                                slab_stride, slab_stride, grad);
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, slab_stride));
         }
         sg_prof_begin(ctx, SG_PROF_DISC_ADAM);
         hipLaunchKernelGGL(k_disc_adam, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v,
-                           world > 1 ? grad : d->d_slabs, world > 1 ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
+                           ctx->use_comm ? grad : d->d_slabs, ctx->use_comm ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
                            a.inv_B, a.lambda_, d->d_loss_acc);
         sg_prof_end(ctx, SG_PROF_DISC_ADAM);
     }
@@ -791,9 +792,9 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     d->returns_none = false;
     const double n_global = (double)N * ctx->world;
     hipLaunchKernelGGL(k_batch_stats, dim3(T), dim3(256), 0, ctx->stream, rets, N, n_global, stats, 0);
-    if (ctx->world > 1) SG_TRY(sg_comm_allreduce_f64(ctx, stats, T));            // per-step sums over all ranks
+    if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats, T));            // per-step sums over all ranks
     hipLaunchKernelGGL(k_batch_stats, dim3(T), dim3(256), 0, ctx->stream, rets, N, n_global, stats, 1);
-    if (ctx->world > 1) SG_TRY(sg_comm_allreduce_f64(ctx, stats + T, T));        // squares about the global mean
+    if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats + T, T));        // squares about the global mean
     hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(1), 0, ctx->stream, stats, T, n_global, rms, scale);
     hipLaunchKernelGGL(k_normalize_rewards, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, ctx->stream, rewards, scale, T, N);
     SG_CHECK(hipGetLastError());

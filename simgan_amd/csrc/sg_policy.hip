@@ -351,11 +351,14 @@ struct PpoArgs {
     int wbuf_floats, ldPmax;
 };
 
-template <int MT>
+// KO = pad16(obs)/16, KH = pad16(hidden)/16 as compile-time constants (0 = run-time shape): fixes
+// every GEMM extent so the tile engine's K/N dispatch folds away (see k_disc_grad).
+template <int MT, int KO, int KH>
 __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
-    const SgPolicyDesc& d = a.d;
+    SgPolicyDesc d = a.d;
+    if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
     const int part = blockIdx.y;
     const int t0 = part == 0 ? 0 : d.n_trunks - 1;
     const int nt = part == 0 ? d.n_trunks - 1 : 1;
@@ -536,6 +539,23 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
         if (part == 1) ls[0] = acc_lv;
         else { ls[1] = acc_la; ls[2] = acc_le; }
     }
+}
+
+// shape-specialised instances for the shipped configurations at the
+// tile height the launch heuristics pick for them, plus run-time-shape fallbacks
+static void launch_ppo_grad(int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, hipStream_t st, const PpoArgs& pa) {
+    const int ko = d.Op / 16, kh = d.Hp / 16;
+#define SG_PPO_CASE(mt, o, h) \
+    if (MT == mt && ko == o && kh == h) { hipLaunchKernelGGL((k_ppo_grad<mt, o, h>), grid, dim3(256), lds, st, pa); return; }
+    SG_PPO_CASE(2, 3, 4)   // north-star synthetic: obs 47, h64
+    SG_PPO_CASE(4, 3, 4)
+    SG_PPO_CASE(2, 1, 7)   // HopperCombined: obs 14, h100
+    SG_PPO_CASE(1, 4, 7)   // LaikagoCombined: obs 64, h100
+    SG_PPO_CASE(2, 7, 4)   // Laikago refinement: obs 111, h64
+#undef SG_PPO_CASE
+    if (MT == 4) hipLaunchKernelGGL((k_ppo_grad<4, 0, 0>), grid, dim3(256), lds, st, pa);
+    else if (MT == 2) hipLaunchKernelGGL((k_ppo_grad<2, 0, 0>), grid, dim3(256), lds, st, pa);
+    else hipLaunchKernelGGL((k_ppo_grad<1, 0, 0>), grid, dim3(256), lds, st, pa);
 }
 
 static size_t ppo_lds_bytes(const SgPolicyDesc& d, int MT) {
@@ -788,13 +808,13 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     double* stats = a->d_loss_acc + 4;
     hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(1024), 0, ctx->stream, r->d_field[SG_F_RETURNS],
                        r->d_field[SG_F_VALUE_PREDS], TN, adv, stats, 0, 0);
-    if (world > 1) {
+    if (ctx->use_comm) {
         // stats[0] = sum, stats[2] = n are linear: all-reduce, then every rank uses the global mean
         SG_TRY(sg_comm_allreduce_f64(ctx, stats, 3));
     }
     hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(1024), 0, ctx->stream, r->d_field[SG_F_RETURNS],
                        r->d_field[SG_F_VALUE_PREDS], TN, adv, stats, 1, 0);
-    if (world > 1) {
+    if (ctx->use_comm) {
         // only stats[1] (sum of squares about the global mean) must be reduced now; keep sum and n
         SG_TRY(sg_comm_allreduce_f64(ctx, stats + 1, 1));
     }
@@ -849,15 +869,13 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         for (int k = 0; k < M; ++k) {
             pa.perm = a->d_perms + (size_t)e * TN + (size_t)k * mb;
             sg_prof_begin(ctx, SG_PROF_PPO_GRAD);
-            if (MT == 4) hipLaunchKernelGGL(k_ppo_grad<4>, dim3(G, 2), dim3(256), lds, ctx->stream, pa);
-            else if (MT == 2) hipLaunchKernelGGL(k_ppo_grad<2>, dim3(G, 2), dim3(256), lds, ctx->stream, pa);
-            else hipLaunchKernelGGL(k_ppo_grad<1>, dim3(G, 2), dim3(256), lds, ctx->stream, pa);
+            launch_ppo_grad(MT, d, dim3(G, 2), lds, ctx->stream, pa);
             sg_prof_end(ctx, SG_PROF_PPO_GRAD);
             sg_prof_begin(ctx, SG_PROF_PPO_REDUCE);
             hipLaunchKernelGGL(k_ppo_reduce, dim3(nblk), dim3(256), 0, ctx->stream, a->d_slabs, G, slab_stride,
                                d.total, a->d_grad, a->d_part, st);
             sg_prof_end(ctx, SG_PROF_PPO_REDUCE);
-            if (world > 1) {
+            if (ctx->use_comm) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
                 hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
             }

@@ -200,7 +200,7 @@ extern "C" int sg_rollout_count_dones(sg_rollout* r, double* dones) {
     hipLaunchKernelGGL(k_count_dones, dim3(1), dim3(1024), 0, r->ctx->stream, r->d_field[SG_F_MASKS],
                        (int64_t)(r->T + 1) * r->N, d_out);
     SG_CHECK(hipGetLastError());
-    if (r->ctx->world > 1) SG_TRY(sg_comm_allreduce_f64(r->ctx, d_out, 1));
+    if (r->ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(r->ctx, d_out, 1));
     SG_CHECK(hipMemcpyAsync(dones, d_out, sizeof(double), hipMemcpyDeviceToHost, r->ctx->stream));
     SG_CHECK(hipStreamSynchronize(r->ctx->stream));
     return 0;
