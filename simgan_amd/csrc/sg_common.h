@@ -105,9 +105,19 @@ struct sg_ctx {
 
 int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out);
 int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out);
-// profiling helpers: bracket a launch with events when ctx->profile is on
-void sg_prof_begin(sg_ctx* ctx, int which);
-void sg_prof_end(sg_ctx* ctx, int which);
+// Profiling: when ctx->profile is on, a launch is given a start/stop event pair through
+// hipExtLaunchKernelGGL, which timestamps the kernel's own begin and end on the device (the same
+// quantity rocprofv3 --kernel-trace reports), not the gaps around it.  Off: null events.
+struct SgEv { hipEvent_t a = nullptr, b = nullptr; };
+SgEv sg_prof_events(sg_ctx* ctx, int which);
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#define SG_LAUNCH(ctx, which, kernel, grid, block, lds, ...)                                              \
+    do {                                                                                                  \
+        SgEv _ev = sg_prof_events(ctx, which);                                                            \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, _ev.a, _ev.b, 0, __VA_ARGS__);     \
+    } while (0)
+#endif
 
 struct sg_policy {
     sg_ctx* ctx;

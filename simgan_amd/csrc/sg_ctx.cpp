@@ -102,16 +102,13 @@ static hipEvent_t take_event(sg_ctx* ctx) {
     return e;
 }
 
-void sg_prof_begin(sg_ctx* ctx, int which) {
-    if (!ctx->profile) return;
-    hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
-    (void)hipEventRecord(e0, ctx->stream);
-    ctx->prof[which].pending.emplace_back(e0, e1);
-}
-
-void sg_prof_end(sg_ctx* ctx, int which) {
-    if (!ctx->profile) return;
-    (void)hipEventRecord(ctx->prof[which].pending.back().second, ctx->stream);
+SgEv sg_prof_events(sg_ctx* ctx, int which) {
+    SgEv ev;
+    if (!ctx->profile || which < 0) return ev;
+    ev.a = take_event(ctx);
+    ev.b = take_event(ctx);
+    ctx->prof[which].pending.emplace_back(ev.a, ev.b);
+    return ev;
 }
 
 static void prof_drain(sg_ctx* ctx) {

@@ -315,12 +315,13 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_grad(DiscArgs a) {
 
 // shape-specialised instances: north-star / Laikago (F 86, Hd 100), Hopper (F 25, Hd 100), the
 // tiny test shape, and the run-time-shape fallback
-static void launch_disc_grad(const SgDiscDesc& dd, dim3 grid, size_t lds, hipStream_t stream, const DiscArgs& a) {
+static void launch_disc_grad(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
-    if (kf == 6 && kh == 7) hipLaunchKernelGGL((k_disc_grad<6, 7>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
-    else if (kf == 2 && kh == 7) hipLaunchKernelGGL((k_disc_grad<2, 7>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
-    else if (kf == 1 && kh == 1) hipLaunchKernelGGL((k_disc_grad<1, 1>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL((k_disc_grad<0, 0>), grid, dim3(SG_DISC_THREADS), lds, stream, a);
+    const dim3 block(SG_DISC_THREADS);
+    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<6, 7>), grid, block, lds, a);
+    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<2, 7>), grid, block, lds, a);
+    else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<1, 1>), grid, block, lds, a);
+    else SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<0, 0>), grid, block, lds, a);
 }
 
 // out[i] = sum over slabs (data-parallel mode: feeds the all-reduce)
@@ -669,19 +670,15 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
         a.eperm = d->d_eperm + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
         a.alpha = d->d_alpha + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
         a.pperm = d->d_pperm + (size_t)k * B_loc;
-        sg_prof_begin(ctx, SG_PROF_DISC_GRAD);
-        launch_disc_grad(dd, dim3(2 * G), lds, ctx->stream, a);
-        sg_prof_end(ctx, SG_PROF_DISC_GRAD);
+        launch_disc_grad(ctx, dd, dim3(2 * G), lds, a);
         if (ctx->use_comm) {
             hipLaunchKernelGGL(k_slab_sum, dim3((slab_stride + 255) / 256), dim3(256), 0, ctx->stream, d->d_slabs, 2 * G,
                                slab_stride, slab_stride, grad);
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, slab_stride));
         }
-        sg_prof_begin(ctx, SG_PROF_DISC_ADAM);
-        hipLaunchKernelGGL(k_disc_adam, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v,
-                           ctx->use_comm ? grad : d->d_slabs, ctx->use_comm ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
-                           a.inv_B, a.lambda_, d->d_loss_acc);
-        sg_prof_end(ctx, SG_PROF_DISC_ADAM);
+        SG_LAUNCH(ctx, SG_PROF_DISC_ADAM, k_disc_adam, dim3(nblk), dim3(256), 0, d->d_params, d->d_m, d->d_v,
+                  ctx->use_comm ? grad : d->d_slabs, ctx->use_comm ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
+                  a.inv_B, a.lambda_, d->d_loss_acc);
     }
     SG_CHECK(hipGetLastError());
     double acc[3];
@@ -697,9 +694,7 @@ static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, f
     f.d = d->desc; f.params = d->d_params; f.x = d_x; f.n = n; f.offset = offset; f.reward = d_reward;
     int grid = (n + 31) / 32;
     if (grid > 2 * ctx->num_cu) grid = 2 * ctx->num_cu;
-    sg_prof_begin(ctx, SG_PROF_RELABEL);
-    hipLaunchKernelGGL(k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), ctx->stream, f);
-    sg_prof_end(ctx, SG_PROF_RELABEL);
+    SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), f);
     SG_CHECK(hipGetLastError());
     return 0;
 }

@@ -17,6 +17,7 @@
 //   k_ppo_reduce  sums the slabs per parameter, emits per-block sum-of-squares, bumps Adam's t.
 //   k_ppo_adam    global-norm clip (max_norm/(norm+1e-6), clamped to 1) + Adam.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
     float* RET = p; p += R;
     int* VALID = reinterpret_cast<int*>(p); p += R;
     int* IDX = reinterpret_cast<int*>(p); p += R;
+    float* ROWL = p; p += 2 * R;   // per-row loss terms
 
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
     const int row_begin = blockIdx.x * a.rows_per_wg;
@@ -425,78 +427,94 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
             trunk_forward<MT>(d, tr, W, X, H1[ti], H2[ti], OUT[ti], ldP);
         }
         __syncthreads();
-        // ---- loss and d(loss)/d(head outputs), one lane per row (a2c/algo/ppo.py:92-106)
-        if (wave == 0) {
-            float lv = 0.f, la = 0.f, le = 0.f;
-            const int r = lane;
-            if (r < R) {
-                const bool valid = VALID[r];
-                if (part == 1) {
-                    const float v = OUT[0][r * ldP];
-                    float dv = 0.f;
-                    if (valid) {
-                        const float Rt = RET[r], vo = VPRED[r];
-                        if (a.use_clipped) {
-                            const float dvv = v - vo;
-                            const float vc = vo + fminf(fmaxf(dvv, -a.clip), a.clip);
-                            const float u = (v - Rt) * (v - Rt), w = (vc - Rt) * (vc - Rt);
-                            const float m1 = u > w ? 1.f : (u < w ? 0.f : 0.5f);
-                            const float pass = (dvv >= -a.clip && dvv <= a.clip) ? 1.f : 0.f;
-                            dv = 0.5f * a.inv_B * (m1 * 2.f * (v - Rt) + (1.f - m1) * 2.f * (vc - Rt) * pass);
-                            lv = 0.5f * fmaxf(u, w);
-                        } else {
-                            dv = 0.5f * a.inv_B * (-2.f) * (Rt - v);
-                            lv = 0.5f * (Rt - v) * (Rt - v);
-                        }
-                        dv *= a.vcoef;
+        // ---- loss and d(loss)/d(head outputs)  (a2c/algo/ppo.py:92-106)
+        if (part == 1) {
+            // critic: one lane per row
+            if (tid < R) {
+                const int r = tid;
+                const float v = OUT[0][r * ldP];
+                float dv = 0.f, lv = 0.f;
+                if (VALID[r]) {
+                    const float Rt = RET[r], vo = VPRED[r];
+                    if (a.use_clipped) {
+                        const float dvv = v - vo;
+                        const float vc = vo + fminf(fmaxf(dvv, -a.clip), a.clip);
+                        const float u = (v - Rt) * (v - Rt), w = (vc - Rt) * (vc - Rt);
+                        const float m1 = u > w ? 1.f : (u < w ? 0.f : 0.5f);
+                        const float pass = (dvv >= -a.clip && dvv <= a.clip) ? 1.f : 0.f;
+                        dv = 0.5f * a.inv_B * (m1 * 2.f * (v - Rt) + (1.f - m1) * 2.f * (vc - Rt) * pass);
+                        lv = 0.5f * fmaxf(u, w);
+                    } else {
+                        dv = 0.5f * a.inv_B * (-2.f) * (Rt - v);
+                        lv = 0.5f * (Rt - v) * (Rt - v);
                     }
-                    OUT[0][r * ldP] = dv;
-                } else {
-                    const SgTrunk tra = d.trunk[0];
-                    float* o0 = OUT[0] + r * ldP;
-                    float* o1 = OUT[1] + r * ldP;
-                    const float* act = ACT + r * A;
-                    const bool mlp = d.kind == SG_POLICY_MLP;
-                    float logp = 0.f, ent = 0.f;
-                    for (int k = 0; k < A; ++k) {
+                    dv *= a.vcoef;
+                }
+                OUT[0][r * ldP] = dv;
+                ROWL[r] = lv;
+            }
+        } else {
+            // actor(s): 32 lanes per row, one action dimension per lane; log-prob / entropy summed
+            // across the row's lanes with shuffles, every lane then forms its own d/dmean, d/dlogstd
+            const SgTrunk tra = d.trunk[0];
+            const bool mlp = d.kind == SG_POLICY_MLP;
+            const int rows_per_pass = blockDim.x >> 5;
+            for (int r = tid >> 5; r < R; r += rows_per_pass) {
+                float* o0 = OUT[0] + r * ldP;
+                float* o1 = OUT[1] + r * ldP;
+                float logp = 0.f, ent = 0.f;
+                for (int k0 = 0; k0 < A; k0 += 32) {       // A <= 32 for every shipped policy: one trip
+                    const int k = k0 + (tid & 31);
+                    float lp = 0.f, en = 0.f;
+                    if (k < A) {
                         float mean, ls;
                         if (mlp) { mean = o0[k]; ls = W[tra.ex + k]; }
                         else if (k < d.nc) { mean = o0[k]; ls = o0[d.nc + k]; }
                         else { mean = o1[k - d.nc]; ls = o1[d.na + k - d.nc]; }
-                        const float sigma = expf(ls), diff = act[k] - mean;
-                        logp += -(diff * diff) / (2.f * sigma * sigma) - logf(sigma) - HALF_LOG_2PI;
-                        ent += 0.5f + HALF_LOG_2PI + logf(sigma);
+                        const float sigma = expf(ls), diff = ACT[r * A + k] - mean, lsig = logf(sigma);
+                        lp = -(diff * diff) / (2.f * sigma * sigma) - lsig - HALF_LOG_2PI;
+                        en = 0.5f + HALF_LOG_2PI + lsig;
                     }
-                    float dlogp = 0.f;
-                    if (valid) {
-                        const float adv = ADV[r];
-                        const float ratio = expf(logp - OLDLP[r]);
-                        const float surr1 = ratio * adv;
-                        const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
-                        const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);
-                        const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
-                        dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
-                        la = -fminf(surr1, surr2);
-                        le = ent;
-                    }
-                    const float dent = valid ? a.ecoef * a.inv_B : 0.f;
-                    for (int k = 0; k < A; ++k) {
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); }
+                    logp += lp;
+                    ent += en;
+                }
+                const bool valid = VALID[r];
+                float dlogp = 0.f, la = 0.f;
+                if (valid) {
+                    const float adv = ADV[r];
+                    const float ratio = expf(logp - OLDLP[r]);
+                    const float surr1 = ratio * adv;
+                    const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
+                    const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);
+                    const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
+                    dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
+                    la = -fminf(surr1, surr2);
+                }
+                const float dent = valid ? a.ecoef * a.inv_B : 0.f;
+                for (int k0 = 0; k0 < A; k0 += 32) {
+                    const int k = k0 + (tid & 31);
+                    if (k < A) {
                         float mean, ls, *pm, *pl;
                         if (mlp) { mean = o0[k]; ls = W[tra.ex + k]; pm = o0 + k; pl = o1 + k; }
                         else if (k < d.nc) { pm = o0 + k; pl = o0 + d.nc + k; mean = *pm; ls = *pl; }
                         else { pm = o1 + (k - d.nc); pl = o1 + (d.na + k - d.nc); mean = *pm; ls = *pl; }
-                        const float sigma = expf(ls), var = sigma * sigma, diff = act[k] - mean;
+                        const float sigma = expf(ls), var = sigma * sigma, diff = ACT[r * A + k] - mean;
                         *pm = dlogp * diff / var;
                         *pl = dlogp * (diff * diff / var - 1.f) - dent;
+                    } else if (mlp && k < tra.Pp) {
+                        o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
                     }
-                    if (mlp)  // o1 doubles as the per-row d/d logstd tile: clear its padding columns
-                        for (int k = A; k < tra.Pp; ++k) o1[k] = 0.f;
                 }
+                if ((tid & 31) == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
             }
-            lv = sg_wave_sum(lv); la = sg_wave_sum(la); le = sg_wave_sum(le);
-            acc_lv += lv; acc_la += la; acc_le += le;
         }
         __syncthreads();
+        if (tid == 0) {
+            if (part == 1) { for (int r = 0; r < R; ++r) acc_lv += ROWL[r]; }
+            else { for (int r = 0; r < R; ++r) { acc_la += ROWL[r]; acc_le += ROWL[R + r]; } }
+        }
         // ---- backward, trunks in reverse so the last-staged trunk is still resident
         for (int ti = nt - 1; ti >= 0; --ti) {
             const SgTrunk tr = d.trunk[t0 + ti];
@@ -514,23 +532,32 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
             sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, accumulate);
             if (tr.EX) sg_colsum(OUT[1], ldP, R, SG_PAD16(tr.EX), g + tr.ex, accumulate);
             __syncthreads();
-            // dZ2 = (dOUT Wh) * (1 - h2^2), in place over h2
-            sg_layer_nn<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, d.Hp, [&](int r, int c, float v) {
-                const float h = h2[r * ldH + c];
-                h2[r * ldH + c] = v * (1.f - h * h);
-            });
+            // dZ = (dY W) * (1 - h^2) in place over h; the bias gradient (column sum of dZ) falls out
+            // of the epilogue registers
+            auto dz_epilogue = [&](float* h, float* gb) {
+                return [=](int tn, f32x4 (&acc)[MT][1]) {
+                    const int c = tn * 16 + (tid & 15), lq = (tid & 63) >> 4;
+                    float z[MT][4];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* ph = h + (i * 16 + 4 * lq + r) * ldH + c;
+                            const float hv = *ph;
+                            z[i][r] = acc[i][0][r] * (1.f - hv * hv);
+                            *ph = z[i][r];
+                        }
+                    const float sb = sg_tile_colsum<MT>(z);
+                    if (lq == 0) gb[c] = accumulate ? gb[c] + sb : sb;
+                };
+            };
+            sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, d.Hp, dz_epilogue(h2, g + tr.b2));
             __syncthreads();
             sg_grad_tn<MT>(h2, ldH, h1, ldH, d.Hp, d.Hp, g + tr.w2, ldH, accumulate);
-            sg_colsum(h2, ldH, R, d.Hp, g + tr.b2, accumulate);
             __syncthreads();
-            // dZ1 = (dZ2 W2) * (1 - h1^2), in place over h1
-            sg_layer_nn<MT>(h2, ldH, W + tr.w2, ldH, d.Hp, d.Hp, [&](int r, int c, float v) {
-                const float h = h1[r * ldH + c];
-                h1[r * ldH + c] = v * (1.f - h * h);
-            });
+            sg_layer_nn_t<MT>(h2, ldH, W + tr.w2, ldH, d.Hp, d.Hp, dz_epilogue(h1, g + tr.b1));
             __syncthreads();
             sg_grad_tn<MT>(h1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, accumulate);
-            sg_colsum(h1, ldH, R, d.Hp, g + tr.b1, accumulate);
             __syncthreads();
         }
     }
@@ -543,19 +570,20 @@ __global__ __launch_bounds__(256) void k_ppo_grad(PpoArgs a) {
 
 // shape-specialised instances for the shipped configurations at the
 // tile height the launch heuristics pick for them, plus run-time-shape fallbacks
-static void launch_ppo_grad(int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, hipStream_t st, const PpoArgs& pa) {
+static void launch_ppo_grad(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
+    const dim3 block(256);
 #define SG_PPO_CASE(mt, o, h) \
-    if (MT == mt && ko == o && kh == h) { hipLaunchKernelGGL((k_ppo_grad<mt, o, h>), grid, dim3(256), lds, st, pa); return; }
+    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_grad<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_CASE(2, 3, 4)   // north-star synthetic: obs 47, h64
     SG_PPO_CASE(4, 3, 4)
     SG_PPO_CASE(2, 1, 7)   // HopperCombined: obs 14, h100
     SG_PPO_CASE(1, 4, 7)   // LaikagoCombined: obs 64, h100
     SG_PPO_CASE(2, 7, 4)   // Laikago refinement: obs 111, h64
 #undef SG_PPO_CASE
-    if (MT == 4) hipLaunchKernelGGL((k_ppo_grad<4, 0, 0>), grid, dim3(256), lds, st, pa);
-    else if (MT == 2) hipLaunchKernelGGL((k_ppo_grad<2, 0, 0>), grid, dim3(256), lds, st, pa);
-    else hipLaunchKernelGGL((k_ppo_grad<1, 0, 0>), grid, dim3(256), lds, st, pa);
+    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_grad<4, 0, 0>), grid, block, lds, pa);
+    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_grad<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_grad<1, 0, 0>), grid, block, lds, pa);
 }
 
 static size_t ppo_lds_bytes(const SgPolicyDesc& d, int MT) {
@@ -563,7 +591,7 @@ static size_t ppo_lds_bytes(const SgPolicyDesc& d, int MT) {
     const int nt_actor = d.n_trunks - 1;
     const int wbuf = max_trunk_size(d, 0, d.n_trunks);
     (void)nt_actor;
-    size_t f = (size_t)wbuf + R * d.ldO + 2 * (2 * R * d.ldH + R * max_ldP(d)) + ((R * d.A + 3) & ~3) + 6 * R;
+    size_t f = (size_t)wbuf + R * d.ldO + 2 * (2 * R * d.ldH + R * max_ldP(d)) + ((R * d.A + 3) & ~3) + 8 * R;
     return sizeof(float) * f;
 }
 
@@ -837,6 +865,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
 
     // launch geometry
     int rows_per_wg = (mb + (ctx->num_cu / 2) - 1) / (ctx->num_cu / 2);
+    if (const char* e = getenv("SG_PPO_ROWS")) {   // tuning knob: rows of the minibatch per workgroup
+        const int v = atoi(e);
+        if (v >= 16) rows_per_wg = v;
+    }
     int MT = ppo_pick_mt(ctx, d, rows_per_wg);
     const int R = 16 * MT;
     rows_per_wg = ((rows_per_wg + R - 1) / R) * R;
@@ -868,22 +900,16 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     for (int e = 0; e < E; ++e)
         for (int k = 0; k < M; ++k) {
             pa.perm = a->d_perms + (size_t)e * TN + (size_t)k * mb;
-            sg_prof_begin(ctx, SG_PROF_PPO_GRAD);
-            launch_ppo_grad(MT, d, dim3(G, 2), lds, ctx->stream, pa);
-            sg_prof_end(ctx, SG_PROF_PPO_GRAD);
-            sg_prof_begin(ctx, SG_PROF_PPO_REDUCE);
-            hipLaunchKernelGGL(k_ppo_reduce, dim3(nblk), dim3(256), 0, ctx->stream, a->d_slabs, G, slab_stride,
-                               d.total, a->d_grad, a->d_part, st);
-            sg_prof_end(ctx, SG_PROF_PPO_REDUCE);
+            launch_ppo_grad(ctx, MT, d, dim3(G, 2), lds, pa);
+            SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
+                      d.total, a->d_grad, a->d_part, st);
             if (ctx->use_comm) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
                 hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
             }
-            sg_prof_begin(ctx, SG_PROF_PPO_ADAM);
-            hipLaunchKernelGGL(k_ppo_adam, dim3(nblk), dim3(256), 0, ctx->stream, a->policy->d_params, a->d_m,
-                               a->d_v, a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm,
-                               inv_mb, a->d_loss_acc);
-            sg_prof_end(ctx, SG_PROF_PPO_ADAM);
+            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m,
+                      a->d_v, a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm,
+                      inv_mb, a->d_loss_acc);
         }
     SG_CHECK(hipGetLastError());
     double acc[3];
