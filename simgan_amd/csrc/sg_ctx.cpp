@@ -1,6 +1,7 @@
 // sg_ctx.cpp -- context, error reporting, scratch arenas, HIP-event profiling slots.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "sg_common.h"
@@ -19,6 +20,11 @@ extern "C" const char* sg_version(void) { return "simgan_hip 0.1 (gfx950)"; }
 
 extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     SG_REQUIRE(out != nullptr, "sg_ctx_create: out is NULL");
+    // Kernel arguments in device memory instead of host-coherent memory: every kernel of the
+    // 5,000-launch update chain starts by reading its kernarg segment, and that first scalar load
+    // is a PCIe round trip otherwise.  Must be in the environment before the HIP runtime
+    // initialises; an explicit user setting wins.
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
     int count = 0;
     SG_CHECK(hipGetDeviceCount(&count));
     SG_REQUIRE(device >= 0 && device < count, "sg_ctx_create: device %d out of range (%d visible)", device, count);

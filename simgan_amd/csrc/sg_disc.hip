@@ -10,7 +10,7 @@
 //                                             a2c/baselines/common/running_mean_std.py:27-58
 //
 // One optimizer step = two launches queued back to back (n_d * gail_epoch of them per update):
-//   k_disc_grad   2*G workgroups, G = ceil(batch/16).  Workgroups [0,G) take 16 expert + 16 policy
+//   k_disc_chain   2*G workgroups, G = ceil(batch/16).  Workgroups [0,G) take 16 expert + 16 policy
 //                 rows through forward/BCE/backward; workgroups [G,2G) take the 16 matching mixup
 //                 rows through forward, input-gradient, penalty and the double backward.  The whole
 //                 parameter vector (its HBM image is the LDS image) is staged once per workgroup;
@@ -33,346 +33,17 @@
 
 int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_t stream_id);
 
-struct DiscArgs {
-    SgDiscDesc d;
-    const float* params;
-    const float* expert;     // [n_expert, F]
-    const float* next_feat;  // obs_feat[1:] flattened [T*N, F]
-    const int64_t* eperm;    // this step's expert row ids  [B]
-    const int64_t* pperm;    // this step's policy row ids  [B]
-    const float* alpha;      // [B]
-    int B;                   // local rows of this step
-    int G;                   // ceil(B/16)
-    float inv_B;             // 1 / global batch rows
-    float lambda_;
-    float* slabs;
-    int slab_stride;
-    SgOptState* st;
-    long long* dbg;          // optional phase timestamps [block][32] (test hook), NULL in production
-};
-
-// barrier + (test hook) shader-clock timestamp of the phase that just ended
-#define SG_PHASE_SYNC(n)                                                         \
-    do {                                                                         \
-        __syncthreads();                                                         \
-        if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 32 + (n)] = clock64(); \
-    } while (0)
-
-__device__ __forceinline__ float sg_log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-
-static size_t disc_grad_lds_bytes(const SgDiscDesc& d) {
-    const size_t bce = (size_t)32 * d.ldF + 3 * 32 * d.ldH + 64;
-    const size_t mix = (size_t)2 * 16 * d.ldF + 7 * 16 * d.ldH + 64;
-    return sizeof(float) * ((size_t)d.total + (bce > mix ? bce : mix));
-}
-
-// sum over the L (power of two, <= 64) consecutive lanes that share a row
-__device__ __forceinline__ float sg_rowlane_sum(float s, int L) {
-    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o);
-    return s;
-}
-
-#define SG_DISC_THREADS 512
-
-// KF = pad16(F)/16 and KH = pad16(Hd)/16 as compile-time constants (0 = take them from the
-// descriptor at run time): with the shape fixed, every GEMM extent, LDS offset and staging trip
-// count folds to a constant, the K/N dispatch switches of the tile engine collapse to the one
-// body needed, and the kernel's code shrinks ~6x (it has to stay resident in the 64 KB I-cache).
-template <int KF, int KH>
-__global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_grad(DiscArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    SgDiscDesc d = a.d;
-    if (KF > 0 && KH > 0) {   // same arithmetic as sg_make_disc_desc
-        d.Fp = 16 * KF; d.ldF = d.Fp + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4;
-        d.w1 = 0; d.b1 = d.Hp * d.ldF; d.w2 = d.b1 + d.Hp; d.b2 = d.w2 + d.Hp * d.ldH;
-        d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
-    }
-    const int tid = threadIdx.x;
-    const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp, F = d.F;
-    float* W = smem;
-    const float* W1 = W + d.w1;
-    const float* b1 = W + d.b1;
-    const float* W2 = W + d.w2;
-    const float* b2 = W + d.b2;
-    const float* w3 = W + d.w3;
-    float* buf = W + d.total;
-    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
-
-    const int li = tid & 15, lq = (tid & 63) >> 4;
-    if ((int)blockIdx.x < a.G) {
-        // ------------------------------------------------ BCE group: rows 0-15 expert, 16-31 policy
-        constexpr int R = 32;
-        const int g = blockIdx.x;
-        float* X = buf;
-        float* H1 = X + R * ldF;
-        float* H2 = H1 + R * ldH;   // h2, then dZ2 in place
-        float* DZ1 = H2 + R * ldH;
-        float* DD = DZ1 + R * ldH;
-        float* LOSS = DD + R;
-        // row gather, 8 elements per lane in flight (index load -> row load are dependent round trips)
-        for (int base = tid; base < R * Fp; base += 8 * blockDim.x) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * blockDim.x;
-                const int r = i / Fp, c = i - r * Fp;
-                const int b = g * 16 + (r & 15);
-                v[u] = 0.f;
-                if (i < R * Fp && b < a.B && c < F)
-                    v[u] = (r < 16) ? a.expert[(size_t)a.eperm[b] * F + c] : a.next_feat[(size_t)a.pperm[b] * F + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * blockDim.x;
-                if (i < R * Fp) X[(i / Fp) * ldF + (i % Fp)] = v[u];
-            }
-        }
-        sg_stage(W, a.params, d.total / 4);
-        SG_PHASE_SYNC(1);
-        // Adam t / bias corrections for the k_disc_adam that follows: one lane of the last wave, which
-        // has no tile in the 7-tile GEMM phases, so the double-precision pow() hides behind them
-        if (blockIdx.x == 0 && tid == (int)blockDim.x - 64) sg_opt_advance(a.st);
-        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
-        SG_PHASE_SYNC(2);
-        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
-        SG_PHASE_SYNC(3);
-        {   // logits, BCE losses and dL/dd: blockDim/32 lanes per row   (a2c/algo/gail.py:168-176)
-            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
-            float s = 0.f;
-            for (int c = sub; c < Hp; c += L) s += H2[r * ldH + c] * w3[c];
-            s = sg_rowlane_sum(s, L);
-            if (sub == 0) {
-                const float dd = s + W[d.b3];
-                const bool valid = g * 16 + (r & 15) < a.B;
-                float loss = 0.f, grad = 0.f;
-                if (valid) {
-                    if (r < 16) { loss = -sg_log_sigmoid(dd); grad = a.inv_B * (sg_sigmoid(dd) - 1.f); }
-                    else { loss = dd - sg_log_sigmoid(dd); grad = a.inv_B * sg_sigmoid(dd); }
-                }
-                DD[r] = grad;
-                LOSS[r] = loss;
-            }
-        }
-        SG_PHASE_SYNC(4);
-        // dw3, db2, db3 and dZ2 (in place over H2), one thread per hidden column
-        for (int c = tid; c < Hp; c += blockDim.x) {
-            const float w = w3[c];
-            float gw = 0.f, gb = 0.f;
-            for (int r = 0; r < R; ++r) {
-                const float h = H2[r * ldH + c], dd = DD[r];
-                gw += dd * h;
-                const float dz = dd * w * (1.f - h * h);
-                gb += dz;
-                H2[r * ldH + c] = dz;
-            }
-            slab[d.w3 + c] = gw;
-            slab[d.b2 + c] = gb;
-        }
-        if (tid >= 256 && tid < 272) {
-            float gb = 0.f;
-            if (tid == 256) for (int r = 0; r < R; ++r) gb += DD[r];
-            slab[d.b3 + tid - 256] = gb;
-        }
-        if (tid == 320) {
-            float le = 0.f, lp = 0.f;
-            for (int r = 0; r < 16; ++r) { le += LOSS[r]; lp += LOSS[16 + r]; }
-            float* ls = slab + d.total;
-            ls[0] = le; ls[1] = lp; ls[2] = 0.f;
-        }
-        SG_PHASE_SYNC(5);
-        // dZ1 = (dZ2 W2) * (1 - h1^2) and db1 in the epilogue; dW2 = dZ2^T h1 alongside
-        sg_layer_nn_t<2>(H2, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[2][1]) {
-            const int c = tn * 16 + li;
-            float z[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i * 16 + 4 * lq + r;
-                    const float h = H1[row * ldH + c];
-                    z[i][r] = acc[i][0][r] * (1.f - h * h);
-                    DZ1[row * ldH + c] = z[i][r];
-                }
-            const float sb = sg_tile_colsum<2>(z);
-            if (lq == 0) slab[d.b1 + c] = sb;
-        });
-        sg_grad_tn<2>(H2, ldH, H1, ldH, Hp, Hp, slab + d.w2, ldH, false);
-        SG_PHASE_SYNC(6);
-        sg_grad_tn<2>(DZ1, ldH, X, ldF, Hp, Fp, slab + d.w1, ldF, false);
-    } else {
-        // ------------------------------------------------ mixup group: gradient penalty on 16 rows
-        constexpr int R = 16;
-        const int g = blockIdx.x - a.G;
-        float* XM = buf;
-        float* GX = XM + R * ldF;   // g, then gb
-        float* H1 = GX + R * ldF;
-        float* H2 = H1 + R * ldH;
-        float* D2 = H2 + R * ldH;   // d2
-        float* U1 = D2 + R * ldH;   // u1, then sb1, then z1b (all in place, element-wise)
-        float* D1 = U1 + R * ldH;   // d1
-        float* BU1 = D1 + R * ldH;  // bu1
-        float* Z2B = BU1 + R * ldH; // z2b
-        float* ROWL = Z2B + R * ldH;
-        for (int base = tid; base < R * Fp; base += 4 * blockDim.x) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * blockDim.x;
-                const int r = i / Fp, c = i - r * Fp;
-                const int b = g * 16 + r;
-                v[u] = 0.f;
-                if (i < R * Fp && b < a.B && c < F) {
-                    const float al = a.alpha[b];
-                    v[u] = al * a.expert[(size_t)a.eperm[b] * F + c] + (1.f - al) * a.next_feat[(size_t)a.pperm[b] * F + c];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * blockDim.x;
-                if (i < R * Fp) XM[(i / Fp) * ldF + (i % Fp)] = v[u];
-            }
-        }
-        sg_stage(W, a.params, d.total / 4);
-        SG_PHASE_SYNC(8);
-        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
-        SG_PHASE_SYNC(9);
-        sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
-            const float h = sg_tanh(v + b2[c]);
-            H2[r * ldH + c] = h;
-            D2[r * ldH + c] = w3[c] * (1.f - h * h);
-        });
-        SG_PHASE_SYNC(10);
-        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {      // u1 = d2 W2
-            const float h = H1[r * ldH + c];
-            U1[r * ldH + c] = v;
-            D1[r * ldH + c] = v * (1.f - h * h);
-        });
-        SG_PHASE_SYNC(11);
-        sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });  // g = d1 W1
-        SG_PHASE_SYNC(12);
-        {   // per-row |g|, penalty and gb = c_r * g: blockDim/16 lanes per row   (a2c/algo/gail.py:88)
-            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
-            float s = 0.f;
-            for (int c = sub; c < Fp; c += L) { const float v = GX[r * ldF + c]; s += v * v; }
-            s = sg_rowlane_sum(s, L);
-            const float nn = sqrtf(s);
-            const bool valid = g * 16 + r < a.B;
-            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
-            for (int c = sub; c < Fp; c += L) GX[r * ldF + c] *= cr;
-            if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
-        }
-        SG_PHASE_SYNC(13);
-        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {      // bd1 = gb W1^T
-            const float h = H1[r * ldH + c];
-            BU1[r * ldH + c] = v * (1.f - h * h);
-            U1[r * ldH + c] = v * U1[r * ldH + c];                                  // sb1 = bd1*u1
-        });
-        SG_PHASE_SYNC(14);
-        sg_layer_nt_t<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // bd2 = bu1 W2^T
-            const int c = tn * 16 + li;
-            const float w = w3[c];
-            float t3[1][4], z[1][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lq + r;
-                const float h = H2[row * ldH + c], s2 = 1.f - h * h, v = acc[0][0][r];
-                t3[0][r] = v * s2;                                                  // -> dw3
-                z[0][r] = (-2.f * h * (v * w)) * s2;                                // z2b
-                Z2B[row * ldH + c] = z[0][r];
-            }
-            const float sw = sg_tile_colsum<1>(t3), sb = sg_tile_colsum<1>(z);
-            if (lq == 0) { slab[d.w3 + c] = sw; slab[d.b2 + c] = sb; }
-        });
-        SG_PHASE_SYNC(15);
-        sg_layer_nn_t<1>(Z2B, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // h1b = z2b W2
-            const int c = tn * 16 + li;
-            float z[1][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lq + r;
-                const float h = H1[row * ldH + c];
-                z[0][r] = (acc[0][0][r] - 2.f * h * U1[row * ldH + c]) * (1.f - h * h);  // z1b
-                U1[row * ldH + c] = z[0][r];
-            }
-            const float sb = sg_tile_colsum<1>(z);
-            if (lq == 0) slab[d.b1 + c] = sb;
-        });
-        sg_grad_tn2<1>(D2, ldH, BU1, ldH, Z2B, H1, Hp, Hp, slab + d.w2, ldH, false);   // dW2 = d2^T bu1 + z2b^T h1
-        SG_PHASE_SYNC(16);
-        sg_grad_tn2<1>(D1, ldH, GX, ldF, U1, XM, Hp, Fp, slab + d.w1, ldF, false);     // dW1 = d1^T gb + z1b^T x
-        if (tid < 16) slab[d.b3 + tid] = 0.f;
-        if (tid == 64) {
-            float lg = 0.f;
-            for (int r = 0; r < R; ++r) lg += ROWL[r];
-            float* ls = slab + d.total;
-            ls[0] = 0.f; ls[1] = 0.f; ls[2] = lg;
-        }
-    }
-    SG_PHASE_SYNC(31);
-}
+#include "sg_disc_kernels.hpp"
 
 // shape-specialised instances: north-star / Laikago (F 86, Hd 100), Hopper (F 25, Hd 100), the
 // tiny test shape, and the run-time-shape fallback
-static void launch_disc_grad(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a) {
+static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     const dim3 block(SG_DISC_THREADS);
-    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<6, 7>), grid, block, lds, a);
-    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<2, 7>), grid, block, lds, a);
-    else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<1, 1>), grid, block, lds, a);
-    else SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_grad<0, 0>), grid, block, lds, a);
-}
-
-// out[i] = sum over slabs (data-parallel mode: feeds the all-reduce)
-__global__ void k_slab_sum(const float* slabs, int n_slabs, int slab_stride, int count, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    float g = 0.f;
-    for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * slab_stride + i];
-    out[i] = g;
-}
-
-// Slab reduction + Adam (torch.optim.Adam defaults: lr 1e-3, betas (0.9, 0.999), eps 1e-8;
-// a2c/algo/gail.py:48,186-188) + running loss sums (a2c/algo/gail.py:181-184).
-__global__ __launch_bounds__(256) void k_disc_adam(float* params, float* m, float* v, const float* slabs,
-                                                   int n_slabs, int slab_stride, int total, const SgOptState* st,
-                                                   float eps, float inv_B, float lambda_, double* loss_acc) {
-    const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        // 16 slab loads in flight per lane (one memory round trip for the usual 2*128/16 slabs);
-        // partial sums are combined in a fixed order, so the result is deterministic
-        float mi = m[i], vi = v[i], pi = params[i];
-        float g = 0.f;
-        for (int s0 = 0; s0 < n_slabs; s0 += 16) {
-            float p[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) p[u] = (s0 + u < n_slabs) ? slabs[(size_t)(s0 + u) * slab_stride + i] : 0.f;
-            g += (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) +
-                 (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
-        }
-        mi = mi + (g - mi) * (float)(1.0 - 0.9);
-        vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
-        const float denom = sqrtf(vi) / s_bc2_sqrt + eps;
-        params[i] = pi - s_step_size * (mi / denom);
-        m[i] = mi;
-        v[i] = vi;
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {  // last block has the fewest parameters
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int s = threadIdx.x; s < n_slabs; s += 64) {
-            const float* ls = slabs + (size_t)s * slab_stride + total;
-            s0 += ls[0]; s1 += ls[1]; s2 += ls[2];
-        }
-        s0 = sg_wave_sum(s0); s1 = sg_wave_sum(s1); s2 = sg_wave_sum(s2);
-        if (threadIdx.x == 0) {
-            const float el = s0 * inv_B, pl = s1 * inv_B, gp = lambda_ * (s2 * inv_B);
-            loss_acc[0] += (double)(el + pl + gp);
-            loss_acc[1] += (double)el;
-            loss_acc[2] += (double)pl;
-        }
-    }
+    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<6, 7>), grid, block, lds, a);
+    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<2, 7>), grid, block, lds, a);
+    else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<1, 1>), grid, block, lds, a);
+    else SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<0, 0>), grid, block, lds, a);
 }
 
 __global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
@@ -500,9 +171,9 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     sg_disc* d = new sg_disc();
     d->ctx = ctx;
     d->desc = sg_make_disc_desc(input_dim, hidden_dim);
-    SG_REQUIRE(disc_grad_lds_bytes(d->desc) <= (size_t)ctx->lds_bytes,
+    SG_REQUIRE(disc_chain_lds_bytes(d->desc) <= (size_t)ctx->lds_bytes,
                "sg_disc_create: discriminator (%d x %d) needs %zu bytes of LDS, the CU has %d", input_dim, hidden_dim,
-               disc_grad_lds_bytes(d->desc), ctx->lds_bytes);
+               disc_chain_lds_bytes(d->desc), ctx->lds_bytes);
     const size_t tot = d->desc.total;
     SG_CHECK(hipMalloc((void**)&d->d_params, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_m, sizeof(float) * tot));
@@ -646,13 +317,15 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     }
 
     const int G = (B_loc + 15) / 16;
-    const int slab_stride = dd.total + 8;
-    if (d->n_slabs < 2 * G + 1) {
+    // scratch of one step: operand stacks | per-workgroup vector partials | (data-parallel) flat gradient
+    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)2 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
+    if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
-        SG_CHECK(hipMalloc((void**)&d->d_slabs, sizeof(float) * (size_t)(2 * G + 1) * slab_stride));
-        d->n_slabs = 2 * G + 1;
-        SG_CHECK(hipMemsetAsync(d->d_slabs, 0, sizeof(float) * (size_t)(2 * G + 1) * slab_stride, ctx->stream));
+        SG_CHECK(hipMalloc((void**)&d->d_slabs, sizeof(float) * (2 * ops_f + part_f + grad_f)));
+        d->n_slabs = G;
+        // ld-padding entries of the flat gradient are never written by k_disc_wgrad: they must read as zero
+        SG_CHECK(hipMemsetAsync(d->d_slabs, 0, sizeof(float) * (2 * ops_f + part_f + grad_f), ctx->stream));
     }
     SG_CHECK(hipMemsetAsync(d->d_loss_acc, 0, sizeof(double) * 3, ctx->stream));
 
@@ -660,25 +333,43 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     a.d = dd; a.params = d->d_params; a.expert = d->d_expert;
     a.next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
     a.B = B_loc; a.G = G; a.inv_B = 1.0f / (float)batch_size; a.lambda_ = 10.0f;
-    a.slabs = d->d_slabs; a.slab_stride = slab_stride; a.st = reinterpret_cast<SgOptState*>(d->d_state);
+    // the operand stacks are double-buffered by step parity: while k_disc_wgrad of step k reads
+    // stacks[k&1], its spare workgroups gather step k+1's input rows into stacks[(k+1)&1]
+    float* stacks[2] = {d->d_slabs, d->d_slabs + ops_f};
+    a.part = d->d_slabs + 2 * ops_f; a.st = reinterpret_cast<SgOptState*>(d->d_state);
     a.dbg = d->d_dbg;
-    const size_t lds = disc_grad_lds_bytes(dd);
+    float* grad = d->d_slabs + 2 * ops_f + part_f;
+    WgradArgs wa;
+    wa.d = dd; wa.part = a.part; wa.G = G; wa.params = d->d_params; wa.m = d->d_m; wa.v = d->d_v;
+    wa.grad_out = ctx->use_comm ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
+    wa.loss_acc = d->d_loss_acc;
+    const size_t lds = disc_chain_lds_bytes(dd);
+    const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
-    float* grad = d->d_slabs + (size_t)(2 * G) * slab_stride;   // data-parallel: reduced gradient "slab"
     for (int k = 0; k < n_d; ++k) {
         // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
         a.eperm = d->d_eperm + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
         a.alpha = d->d_alpha + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
         a.pperm = d->d_pperm + (size_t)k * B_loc;
-        launch_disc_grad(ctx, dd, dim3(2 * G), lds, a);
-        if (ctx->use_comm) {
-            hipLaunchKernelGGL(k_slab_sum, dim3((slab_stride + 255) / 256), dim3(256), 0, ctx->stream, d->d_slabs, 2 * G,
-                               slab_stride, slab_stride, grad);
-            SG_TRY(sg_comm_allreduce_f32(ctx, grad, slab_stride));
+        a.ops = stacks[k & 1];
+        wa.ops = a.ops;
+        PregatherArgs pg;
+        pg.expert = d->d_expert; pg.next_feat = a.next_feat; pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp;
+        pg.ldF = dd.ldF; pg.ldH = dd.ldH;
+        if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
+            pg.eperm = a.eperm; pg.pperm = a.pperm; pg.alpha = a.alpha; pg.ops = a.ops;
+            hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
         }
-        SG_LAUNCH(ctx, SG_PROF_DISC_ADAM, k_disc_adam, dim3(nblk), dim3(256), 0, d->d_params, d->d_m, d->d_v,
-                  ctx->use_comm ? grad : d->d_slabs, ctx->use_comm ? 1 : 2 * G, slab_stride, dd.total, a.st, 1e-8f,
-                  a.inv_B, a.lambda_, d->d_loss_acc);
+        pg.eperm = a.eperm + batch_size; pg.alpha = a.alpha + batch_size; pg.pperm = a.pperm + B_loc;
+        pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
+        wa.next = pg;
+        launch_disc_chain(ctx, dd, dim3(2 * G), lds, a);
+        SG_LAUNCH(ctx, SG_PROF_DISC_ADAM, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
+        if (ctx->use_comm) {
+            SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
+            hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
+                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc);
+        }
     }
     SG_CHECK(hipGetLastError());
     double acc[3];
@@ -798,7 +489,7 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     return 0;
 }
 
-// Test hook: enable/read per-phase shader-clock timestamps of k_disc_grad (tools/phase_times.py).
+// Test hook: enable/read per-phase shader-clock timestamps of k_disc_chain (tools/phase_times.py).
 extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, int n_blocks) {
     SG_REQUIRE(d, "sg_test_disc_phase_times: NULL argument");
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));

@@ -1,0 +1,497 @@
+// sg_disc_kernels.hpp -- device kernels of one GAIL discriminator optimizer step.
+//
+// One step = two launches queued back to back (n_d * gail_epoch of them per update):
+//
+//   k_disc_chain<KF,KH>   2*G workgroups of 512 threads, G = ceil(batch/16).  Workgroups [0,G)
+//       take 16 expert + 16 policy rows through forward / BCE-with-logits / backward-to-
+//       activations; workgroups [G,2G) take the 16 matching mixup rows through forward, the input
+//       gradient, the penalty and its double backward (a2c/algo/gail.py:67-89,165-188).  This is
+//       the serial critical path of the step: a chain of 6 (BCE) or 9 (mixup) dependent LDS-tile
+//       MFMA GEMM phases on the 98 KB parameter image staged in LDS.  It does NOT form weight
+//       gradients: each phase's epilogue drops the operands of dW = dY^T X into two global
+//       "operand stacks" (left = dY-like rows, right = X-like rows), and writes per-workgroup
+//       partial bias / w3 / loss sums.
+//   k_disc_wgrad          one workgroup per 16x16 tile of W1 and W2 (91 at F=86, Hd=100) + one for
+//       the vectors.  dW2 = L2^T R2 and dW1 = L1^T R1 are plain TN GEMMs over the stacked rows
+//       (K = 4*16*G = 512 for batch 128); the 4 waves split K, combine through LDS, and the 256
+//       threads apply torch-Adam to the tile's 256 parameters in place.  The weight-gradient
+//       third of the MFMA work thus runs on ~92 otherwise idle CUs instead of lengthening the
+//       16-workgroup chain, and no gradient slab is written or re-read.
+//
+// Gradient-penalty math (x = mixup row, s_i = 1 - h_i^2, lambda = 10, B = batch):
+//   d2 = w3*s2; u1 = W2^T d2; d1 = u1*s1; g = W1^T d1; n = |g|; gb = lambda*(2/B)*(n-1)/n * g
+//   dW1 += d1 gb^T; bd1 = W1 gb; bu1 = bd1*s1; sb1 = bd1*u1; dW2 += d2 bu1^T; bd2 = W2 bu1
+//   dw3 += bd2*s2; sb2 = bd2*w3; z2b = (-2 h2 sb2)*s2; dW2 += z2b h1^T; db2 += z2b
+//   h1b = W2^T z2b - 2 h1 sb1; z1b = h1b*s1; dW1 += z1b x^T; db1 += z1b
+//
+// Operand stacks (rows Kt = 4*nb, nb = 16*G):            left (dY-like)        right (X-like)
+//   rows [0, 2nb)        BCE workgroup g, local row r      L2: dZ2   L1: dZ1     R2: h1    R1: x
+//   rows [2nb, 3nb)      mixup workgroup g, first term     L2: d2    L1: d1      R2: bu1   R1: gb
+//   rows [3nb, 4nb)      mixup workgroup g, second term    L2: z2b   L1: z1b     R2: h1    R1: x~
+#pragma once
+#include "sg_common.h"
+
+struct DiscArgs {
+    SgDiscDesc d;
+    const float* params;
+    const float* expert;     // [n_expert, F]
+    const float* next_feat;  // obs_feat[1:] flattened [T*N, F]
+    const int64_t* eperm;    // this step's expert row ids  [B]
+    const int64_t* pperm;    // this step's policy row ids  [B]
+    const float* alpha;      // [B]
+    int B;                   // local rows of this step
+    int G;                   // ceil(B/16)
+    float inv_B;             // 1 / global batch rows
+    float lambda_;
+    float* ops;              // operand stacks: L2 | R2 | L1 [Kt][ldH] each, then R1 [Kt][ldF]
+    float* part;             // [2G][4*Hp]: db1 | db2 | dw3 | {db3, loss_expert, loss_policy, loss_gp, 0...}
+    SgOptState* st;
+    long long* dbg;          // optional phase timestamps [block][32] (test hook), NULL in production
+};
+
+// barrier + (test hook) shader-clock timestamp of the phase that just ended
+#define SG_PHASE_SYNC(n)                                                         \
+    do {                                                                         \
+        __syncthreads();                                                         \
+        if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 32 + (n)] = clock64(); \
+    } while (0)
+
+__device__ __forceinline__ float sg_log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// sum over the L (power of two, <= 64) consecutive lanes that share a row
+__device__ __forceinline__ float sg_rowlane_sum(float s, int L) {
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+#define SG_DISC_THREADS 512
+
+static size_t disc_chain_lds_bytes(const SgDiscDesc& d) {
+    const size_t bce = (size_t)32 * d.ldF + 2 * 32 * d.ldH + 64;
+    const size_t mix = (size_t)2 * 16 * d.ldF + 7 * 16 * d.ldH + 64;
+    return sizeof(float) * ((size_t)d.total + (bce > mix ? bce : mix));
+}
+static size_t disc_ops_floats(const SgDiscDesc& d, int G) {
+    const size_t Kt = (size_t)64 * G;
+    return Kt * (3 * (size_t)d.ldH + d.ldF);
+}
+
+// Input rows of ONE chain workgroup of the NEXT step, gathered by permutation index into the right
+// operand stack it will read them from: rows [32g, 32g+32) = 16 expert + 16 policy rows for BCE
+// workgroup g (j < G), rows [3nb+16g, +16) = the alpha-mixed rows for mixup workgroup g (j >= G).
+// The index -> row dependent round trips (a2c/storage.py:168-185 gather, DataLoader batch,
+// a2c/algo/gail.py:72-75 mixup) thereby run beside the previous step's weight-gradient tiles
+// instead of at the head of the serial chain.  Columns [F, Fp) are written as zeros.
+struct PregatherArgs {
+    const float* expert;
+    const float* next_feat;
+    const int64_t* eperm;
+    const int64_t* pperm;
+    const float* alpha;
+    float* ops;     // operand stacks of the step being prepared
+    int B, G, F, Fp, ldF, ldH;
+};
+
+__device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j) {
+    const int nb = 16 * p.G, Kt = 4 * nb;
+    float* R1s = p.ops + (size_t)3 * Kt * p.ldH;
+    const int Fp = p.Fp, F = p.F;
+    const bool bce = j < p.G;
+    const int g = bce ? j : j - p.G;
+    const int rows = bce ? 32 : 16;
+    const int row0 = bce ? 32 * g : 3 * nb + 16 * g;
+    for (int base = threadIdx.x; base < rows * Fp; base += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * blockDim.x;
+            const int r = i / Fp, c = i - r * Fp;
+            const int b = g * 16 + (r & 15);
+            v[u] = 0.f;
+            if (i < rows * Fp && b < p.B && c < F) {
+                if (bce) v[u] = (r < 16) ? p.expert[(size_t)p.eperm[b] * F + c] : p.next_feat[(size_t)p.pperm[b] * F + c];
+                else {
+                    const float al = p.alpha[b];
+                    v[u] = al * p.expert[(size_t)p.eperm[b] * F + c] + (1.f - al) * p.next_feat[(size_t)p.pperm[b] * F + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * blockDim.x;
+            if (i < rows * Fp) R1s[(size_t)(row0 + i / Fp) * p.ldF + (i % Fp)] = v[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_disc_pregather(PregatherArgs p) { sg_disc_pregather(p, blockIdx.x); }
+
+// KF = pad16(F)/16 and KH = pad16(Hd)/16 as compile-time constants (0 = take them from the
+// descriptor at run time): with the shape fixed, every GEMM extent, LDS offset and staging trip
+// count folds to a constant and the K/N dispatch switches of the tile engine collapse to the one
+// body needed (the kernel has to stay resident in the 64 KB instruction cache).
+template <int KF, int KH>
+__global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    SgDiscDesc d = a.d;
+    if (KF > 0 && KH > 0) {   // same arithmetic as sg_make_disc_desc
+        d.Fp = 16 * KF; d.ldF = d.Fp + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4;
+        d.w1 = 0; d.b1 = d.Hp * d.ldF; d.w2 = d.b1 + d.Hp; d.b2 = d.w2 + d.Hp * d.ldH;
+        d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
+    }
+    const int tid = threadIdx.x;
+    const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp, F = d.F;
+    float* W = smem;
+    const float* W1 = W + d.w1;
+    const float* b1 = W + d.b1;
+    const float* W2 = W + d.w2;
+    const float* b2 = W + d.b2;
+    const float* w3 = W + d.w3;
+    float* buf = W + d.total;
+    const int nb = 16 * a.G, Kt = 4 * nb;
+    float* L2s = a.ops;
+    float* R2s = L2s + (size_t)Kt * ldH;
+    float* L1s = R2s + (size_t)Kt * ldH;
+    float* R1s = L1s + (size_t)Kt * ldH;
+    float* part = a.part + (size_t)blockIdx.x * (4 * Hp);   // db1 | db2 | dw3 | scalars
+    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
+
+    const int li = tid & 15, lq = (tid & 63) >> 4;
+    if ((int)blockIdx.x < a.G) {
+        // ------------------------------------------------ BCE group: rows 0-15 expert, 16-31 policy
+        constexpr int R = 32;
+        const int g = blockIdx.x;
+        const int row0 = 32 * g;                 // this workgroup's rows in the operand stacks
+        float* X = buf;
+        float* H1 = X + R * ldF;
+        float* H2 = H1 + R * ldH;   // h2, then dZ2 in place
+        float* DD = H2 + R * ldH;
+        float* LOSS = DD + R;
+        // parameter image: loads issued now (12 x 16 B per lane), committed to LDS after the row gather
+        float4 wv[12];
+        sg_stage_issue<12>(wv, a.params, d.total / 4);
+        // this workgroup's 32 input rows were gathered into the right stack by the previous launch
+        // (sg_disc_pregather): contiguous 16 B loads, no index indirection on the critical path
+        for (int i = tid; i < R * (Fp / 4); i += blockDim.x) {
+            const int r = i / (Fp / 4), c = 4 * (i % (Fp / 4));
+            *reinterpret_cast<float4*>(X + r * ldF + c) = *reinterpret_cast<const float4*>(R1s + (size_t)(row0 + r) * ldF + c);
+        }
+        sg_stage_commit<12>(W, wv, a.params, d.total / 4);
+        SG_PHASE_SYNC(1);
+        // Adam t / bias corrections for the k_disc_wgrad that follows: one lane of the last wave, which
+        // has no tile in the 7-tile GEMM phases, so the double-precision pow() hides behind them
+        if (blockIdx.x == 0 && tid == (int)blockDim.x - 64) sg_opt_advance(a.st);
+        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
+            const float h = sg_tanh(v + b1[c]);
+            H1[r * ldH + c] = h;
+            R2s[(size_t)(row0 + r) * ldH + c] = h;
+        });
+        SG_PHASE_SYNC(2);
+        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        SG_PHASE_SYNC(3);
+        {   // logits, BCE losses and dL/dd: blockDim/32 lanes per row   (a2c/algo/gail.py:168-176)
+            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
+            float s = 0.f;
+            for (int c = sub; c < Hp; c += L) s += H2[r * ldH + c] * w3[c];
+            s = sg_rowlane_sum(s, L);
+            if (sub == 0) {
+                const float dd = s + W[d.b3];
+                const bool valid = g * 16 + (r & 15) < a.B;
+                float loss = 0.f, grad = 0.f;
+                if (valid) {
+                    if (r < 16) { loss = -sg_log_sigmoid(dd); grad = a.inv_B * (sg_sigmoid(dd) - 1.f); }
+                    else { loss = dd - sg_log_sigmoid(dd); grad = a.inv_B * sg_sigmoid(dd); }
+                }
+                DD[r] = grad;
+                LOSS[r] = loss;
+            }
+        }
+        SG_PHASE_SYNC(4);
+        // dw3, db2, db3 and dZ2 (in place over H2, and into the left stack), one thread per hidden column
+        for (int c = tid; c < Hp; c += blockDim.x) {
+            const float w = w3[c];
+            float gw = 0.f, gb = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float h = H2[r * ldH + c], dd = DD[r];
+                gw += dd * h;
+                const float dz = dd * w * (1.f - h * h);
+                gb += dz;
+                H2[r * ldH + c] = dz;
+                L2s[(size_t)(row0 + r) * ldH + c] = dz;
+            }
+            part[2 * Hp + c] = gw;
+            part[Hp + c] = gb;
+        }
+        if (tid >= 256 && tid < 272) {
+            float s = 0.f;
+            if (tid == 256) for (int r = 0; r < R; ++r) s += DD[r];               // db3
+            if (tid == 257) for (int r = 0; r < 16; ++r) s += LOSS[r];            // sum expert BCE
+            if (tid == 258) for (int r = 16; r < 32; ++r) s += LOSS[r];           // sum policy BCE
+            part[3 * Hp + tid - 256] = s;
+        }
+        SG_PHASE_SYNC(5);
+        // dZ1 = (dZ2 W2) * (1 - h1^2) straight to the left stack; db1 from the epilogue registers
+        sg_layer_nn_t<2>(H2, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[2][1]) {
+            const int c = tn * 16 + li;
+            float z[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + 4 * lq + r;
+                    const float h = H1[row * ldH + c];
+                    z[i][r] = acc[i][0][r] * (1.f - h * h);
+                    L1s[(size_t)(row0 + row) * ldH + c] = z[i][r];
+                }
+            const float sb = sg_tile_colsum<2>(z);
+            if (lq == 0) part[c] = sb;
+        });
+    } else {
+        // ------------------------------------------------ mixup group: gradient penalty on 16 rows
+        constexpr int R = 16;
+        const int g = blockIdx.x - a.G;
+        const int rowA = 2 * nb + 16 * g, rowB = 3 * nb + 16 * g;
+        float* XM = buf;
+        float* GX = XM + R * ldF;   // g, then gb
+        float* H1 = GX + R * ldF;
+        float* H2 = H1 + R * ldH;
+        float* D2 = H2 + R * ldH;   // d2
+        float* U1 = D2 + R * ldH;   // u1, then sb1
+        float* D1 = U1 + R * ldH;   // d1
+        float* BU1 = D1 + R * ldH;  // bu1
+        float* Z2B = BU1 + R * ldH; // z2b
+        float* ROWL = Z2B + R * ldH;
+        float4 wv[12];
+        sg_stage_issue<12>(wv, a.params, d.total / 4);
+        for (int i = tid; i < R * (Fp / 4); i += blockDim.x) {   // pre-gathered mixup rows (see above)
+            const int r = i / (Fp / 4), c = 4 * (i % (Fp / 4));
+            *reinterpret_cast<float4*>(XM + r * ldF + c) = *reinterpret_cast<const float4*>(R1s + (size_t)(rowB + r) * ldF + c);
+        }
+        sg_stage_commit<12>(W, wv, a.params, d.total / 4);
+        SG_PHASE_SYNC(8);
+        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
+            const float h = sg_tanh(v + b1[c]);
+            H1[r * ldH + c] = h;
+            R2s[(size_t)(rowB + r) * ldH + c] = h;
+        });
+        SG_PHASE_SYNC(9);
+        sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+            const float h = sg_tanh(v + b2[c]);
+            const float d2 = w3[c] * (1.f - h * h);
+            H2[r * ldH + c] = h;
+            D2[r * ldH + c] = d2;
+            L2s[(size_t)(rowA + r) * ldH + c] = d2;
+        });
+        SG_PHASE_SYNC(10);
+        sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {      // u1 = d2 W2
+            const float h = H1[r * ldH + c];
+            const float d1 = v * (1.f - h * h);
+            U1[r * ldH + c] = v;
+            D1[r * ldH + c] = d1;
+            L1s[(size_t)(rowA + r) * ldH + c] = d1;
+        });
+        SG_PHASE_SYNC(11);
+        sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });  // g = d1 W1
+        SG_PHASE_SYNC(12);
+        {   // per-row |g|, penalty and gb = c_r * g: blockDim/16 lanes per row   (a2c/algo/gail.py:88)
+            const int L = blockDim.x / R, r = tid / L, sub = tid % L;
+            float s = 0.f;
+            for (int c = sub; c < Fp; c += L) { const float v = GX[r * ldF + c]; s += v * v; }
+            s = sg_rowlane_sum(s, L);
+            const float nn = sqrtf(s);
+            const bool valid = g * 16 + r < a.B;
+            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
+            for (int c = sub; c < Fp; c += L) {
+                const float gb = GX[r * ldF + c] * cr;
+                GX[r * ldF + c] = gb;
+                R1s[(size_t)(rowA + r) * ldF + c] = gb;
+            }
+            if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
+        }
+        SG_PHASE_SYNC(13);
+        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {      // bd1 = gb W1^T
+            const float h = H1[r * ldH + c];
+            const float bu1 = v * (1.f - h * h);
+            BU1[r * ldH + c] = bu1;
+            R2s[(size_t)(rowA + r) * ldH + c] = bu1;
+            U1[r * ldH + c] = v * U1[r * ldH + c];                                  // sb1 = bd1*u1
+        });
+        SG_PHASE_SYNC(14);
+        sg_layer_nt_t<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // bd2 = bu1 W2^T
+            const int c = tn * 16 + li;
+            const float w = w3[c];
+            float t3[1][4], z[1][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float h = H2[row * ldH + c], s2 = 1.f - h * h, v = acc[0][0][r];
+                t3[0][r] = v * s2;                                                  // -> dw3
+                z[0][r] = (-2.f * h * (v * w)) * s2;                                // z2b
+                Z2B[row * ldH + c] = z[0][r];
+                L2s[(size_t)(rowB + row) * ldH + c] = z[0][r];
+            }
+            const float sw = sg_tile_colsum<1>(t3), sb = sg_tile_colsum<1>(z);
+            if (lq == 0) { part[2 * Hp + c] = sw; part[Hp + c] = sb; }
+        });
+        SG_PHASE_SYNC(15);
+        sg_layer_nn_t<1>(Z2B, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // h1b = z2b W2
+            const int c = tn * 16 + li;
+            float z[1][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float h = H1[row * ldH + c];
+                z[0][r] = (acc[0][0][r] - 2.f * h * U1[row * ldH + c]) * (1.f - h * h);  // z1b
+                L1s[(size_t)(rowB + row) * ldH + c] = z[0][r];
+            }
+            const float sb = sg_tile_colsum<1>(z);
+            if (lq == 0) part[c] = sb;
+        });
+        if (tid >= 448 && tid < 464) {   // the idle last wave: scalars of this workgroup
+            float s = 0.f;
+            if (tid == 451) for (int r = 0; r < R; ++r) s += ROWL[r];             // sum (|g|-1)^2
+            part[3 * Hp + tid - 448] = s;
+        }
+    }
+    SG_PHASE_SYNC(31);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    SgDiscDesc d;
+    const float* ops;
+    const float* part;
+    int G;
+    float *params, *m, *v;
+    float* grad_out;          // data-parallel mode: write the gradient here instead of applying Adam
+    const SgOptState* st;
+    float eps, inv_B, lambda_;
+    double* loss_acc;
+    PregatherArgs next;       // next step's inputs (next.ops == NULL on the last step)
+};
+
+// torch.optim.Adam single-tensor math (a2c/algo/gail.py:48,186-188: lr 1e-3, eps 1e-8)
+__device__ __forceinline__ void sg_adam_apply(float* p, float* m, float* v, float g, float step_size,
+                                              float bc2_sqrt, float eps) {
+    float mi = *m, vi = *v;
+    mi = mi + (g - mi) * (float)(1.0 - 0.9);
+    vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    *p = *p - step_size * (mi / denom);
+    *m = mi;
+    *v = vi;
+}
+
+#define SG_WGRAD_THREADS 512
+
+__global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
+    __shared__ float red[8][256];
+    const SgDiscDesc& d = a.d;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+    const int nw = blockDim.x >> 6;
+    const int th = d.Hp >> 4, tf = d.Fp >> 4;
+    const int T2 = th * th, T1 = th * tf;
+    const int Kt = 64 * a.G;
+    const int b = blockIdx.x;
+    if (b > T2 + T1) {   // blocks past the tiles and the vector block: prepare the next step's rows
+        if (a.next.ops) sg_disc_pregather(a.next, b - (T2 + T1 + 1));
+        return;
+    }
+    if (b < T2 + T1) {
+        const bool w2 = b < T2;
+        const int t = w2 ? b : b - T2;
+        const int tm = w2 ? t / th : t / tf, tn = w2 ? t % th : t % tf;
+        const int ldp = w2 ? d.ldH : d.ldF;
+        // the tile's 256 parameters and moments: requested first so they arrive with the operands
+        const int idx = (w2 ? d.w2 : d.w1) + (tm * 16 + ((tid & 255) >> 4)) * ldp + tn * 16 + (tid & 15);
+        float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+        if (tid < 256 && !a.grad_out) { p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }
+        const float* L = a.ops + (w2 ? (size_t)0 : (size_t)2 * Kt * d.ldH);
+        const float* Rr = w2 ? a.ops + (size_t)Kt * d.ldH : a.ops + (size_t)3 * Kt * d.ldH;
+        const int ldr = w2 ? d.ldH : d.ldF;
+        // this wave's slice of the stacked rows (Kt / 8 = 8*G rows: a multiple of 16 for even G; the
+        // general case walks 16-row chunks dealt round-robin to waves)
+        const int n_chunks = Kt >> 4;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, alt = acc;
+        for (int c0 = wave; c0 < n_chunks; c0 += 4 * nw) {       // up to 4 chunks = 32 loads in flight per lane
+            float x[4][4], y[4][4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int c = c0 + cc * nw;
+                    const int r = 16 * c + 4 * lq + s;
+                    const bool in = c < n_chunks;
+                    x[cc][s] = in ? L[(size_t)r * d.ldH + tm * 16 + li] : 0.f;
+                    y[cc][s] = in ? Rr[(size_t)r * ldr + tn * 16 + li] : 0.f;
+                }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s & 1) alt = sg_mfma(x[cc][s], y[cc][s], alt);
+                    else acc = sg_mfma(x[cc][s], y[cc][s], acc);
+                }
+        }
+        acc += alt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * lq + r) * 16 + li] = acc[r];
+        __syncthreads();
+        if (tid < 256) {
+            float g = 0.f;
+            for (int w = 0; w < nw; ++w) g += red[w][tid];
+            if (a.grad_out) a.grad_out[idx] = g;
+            else {
+                const float step_size = a.st->step_size, bc2_sqrt = a.st->bc2_sqrt;
+                m0 = m0 + (g - m0) * (float)(1.0 - 0.9);
+                v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
+                const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
+                a.params[idx] = p0 - step_size * (m0 / denom);
+                a.m[idx] = m0;
+                a.v[idx] = v0;
+            }
+        }
+    } else {
+        // vectors: db1 | db2 | dw3 | db3 from the per-workgroup partials, and the loss sums
+        const float step_size = a.st->step_size, bc2_sqrt = a.st->bc2_sqrt;
+        const int Hp = d.Hp, nparts = 2 * a.G, stride = 4 * Hp;
+        for (int i = tid; i < 3 * Hp + 4; i += blockDim.x) {
+            float g = 0.f;
+            for (int s = 0; s < nparts; ++s) g += a.part[(size_t)s * stride + i];
+            if (i < 3 * Hp + 1) {
+                const int idx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
+                if (a.grad_out) a.grad_out[idx] = g;
+                else sg_adam_apply(a.params + idx, a.m + idx, a.v + idx, g, step_size, bc2_sqrt, a.eps);
+            } else {
+                red[0][i - (3 * Hp + 1)] = g;       // loss_expert, loss_policy, loss_gp sums
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.grad_out) {
+                a.grad_out[d.total + 0] = red[0][0]; a.grad_out[d.total + 1] = red[0][1]; a.grad_out[d.total + 2] = red[0][2];
+            } else {
+                // a2c/algo/gail.py:181-184: loss.item() etc. are float32, accumulated in Python doubles
+                const float el = red[0][0] * a.inv_B, pl = red[0][1] * a.inv_B, gp = a.lambda_ * (red[0][2] * a.inv_B);
+                a.loss_acc[0] += (double)(el + pl + gp);
+                a.loss_acc[1] += (double)el;
+                a.loss_acc[2] += (double)pl;
+            }
+        }
+    }
+}
+
+// Data-parallel mode only: Adam from the all-reduced flat gradient (+ loss sums in its tail).
+__global__ __launch_bounds__(256) void k_disc_adam_flat(float* params, float* m, float* v, const float* grad, int total,
+                                                        const SgOptState* st, float eps, float inv_B, float lambda_,
+                                                        double* loss_acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size, st->bc2_sqrt, eps);
+    if (i == 0) {
+        const float el = grad[total] * inv_B, pl = grad[total + 1] * inv_B, gp = lambda_ * (grad[total + 2] * inv_B);
+        loss_acc[0] += (double)(el + pl + gp);
+        loss_acc[1] += (double)el;
+        loss_acc[2] += (double)pl;
+    }
+}

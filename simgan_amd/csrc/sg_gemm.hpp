@@ -406,6 +406,31 @@ __device__ __forceinline__ void sg_stage(float* lds, const float* __restrict__ g
     }
 }
 
+// Split form of sg_stage: issue the global loads of the first U*blockDim float4 into registers
+// now, commit them to LDS later, so the memory round trip overlaps whatever is placed in between
+// (the dependent index->row gather of a minibatch).  The tail beyond U*blockDim, if any, is copied
+// by sg_stage_commit itself.
+template <int U>
+__device__ __forceinline__ void sg_stage_issue(float4 (&v)[U], const float* __restrict__ g, int n4) {
+    const float4* src = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        v[u] = i < n4 ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int U>
+__device__ __forceinline__ void sg_stage_commit(float* lds, const float4 (&v)[U], const float* __restrict__ g, int n4) {
+    float4* dst = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        if (i < n4) dst[i] = v[u];
+    }
+    const int done = U * blockDim.x;
+    if (n4 > done) sg_stage(lds + 4 * done, g + 4 * done, n4 - done);
+}
+
 __device__ __forceinline__ float sg_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
