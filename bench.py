@@ -67,16 +67,19 @@ def algorithmic_work(w, world):
     ppo_flops_row = 2 * (3 * fwd - n_tr * O * H)
     mb = TN // w["M"]
     d_step_flops = (B // world) * d_flops_triple
+    d_wgrad_flops = (B // world) * 2 * 4 * (F * Hd + Hd * Hd)   # dW1, dW2 over expert + policy + 2 mixup terms
+    d_chain_flops = d_step_flops - d_wgrad_flops                 # forward + activation backward + double backward
     ppo_step_flops = mb * ppo_flops_row
     relabel_flops = TN * 2 * Wd
     flops = w["E_d"] * n_d * d_step_flops + w["E_p"] * w["M"] * ppo_step_flops + relabel_flops
     bytes_ = (w["E_d"] * n_d * 2 * (B // world) * F * 4 + TN * (F + 2) * 4 + TN * 20 + TN * 12 +
               w["E_p"] * w["M"] * mb * (O + A + 4) * 4)
-    return dict(n_d=n_d, d_step_flops=d_step_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
+    return dict(n_d=n_d, d_step_flops=d_step_flops, d_chain_flops=d_chain_flops, d_wgrad_flops=d_wgrad_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
                 d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"])
 
 
 def build_problem(sg, w, seed):
+    from simgan_amd.driver import ExpertLoader, GailDynLearner
     rng = np.random.default_rng(seed)
     if w["kind"] == "mlp":
         pol = sg.Policy((w["O"],), Box((w["A"],)), base_kwargs={"recurrent": False, "hidden_size": w["H"]}, seed=seed)
@@ -87,28 +90,11 @@ def build_problem(sg, w, seed):
     ro = sg.RolloutStorage(w["T"], w["N"], (w["O"],), Box((w["A"],)), 1, w["F"])
     ro.device_resident = True
     expert = rng.standard_normal((w["Ne"], w["F"])).astype(np.float32)   # identical on every rank (same seed)
-    disc.set_expert(expert)
-    loader = Loader(None, w["B"])
-    disc._expert_id = id(loader)  # expert already resident
-    return pol, disc, agent, ro, loader, expert
-
-
-def one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world, gail_tar_length=500.0):
-    import ctypes as C
-    from simgan_amd import _lib
-    losses_d = None
-    for _ in range(w["E_d"]):
-        losses_d = disc.update_gail_dyn(loader, ro)
-    dones = C.c_double(0)
-    _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))
-    n_tot = w["N"] * world
-    num_of_dones = dones.value + n_tot / 2
-    d_sa = 1 - num_of_dones / (num_of_dones + (w["T"] * n_tot) / gail_tar_length)
-    r_sa = np.log(d_sa) - np.log(1 - d_sa)
-    disc.relabel_rewards(ro, GAMMA, -r_sa, rms)
-    _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, GAMMA, LAM, 1))
-    losses_p = agent.update(ro)
-    return losses_d, losses_p
+    loader = ExpertLoader(expert, w["B"])
+    disc._bind_loader(loader)          # expert matrix resident in HBM before anything is timed
+    learner = GailDynLearner(pol, agent, disc, ro, loader, gail_batch_size=w["B"], gail_epoch=w["E_d"], gamma=GAMMA,
+                             gae_lambda=LAM, gail_tar_length=500.0)
+    return pol, disc, agent, ro, loader, expert, learner
 
 
 def cpu_baseline(w, expert, budget_s):
@@ -184,21 +170,20 @@ def main():
     pg.init_device_comm(ctx, _lib.comm_unique_id)
 
     w = WORKLOADS[args.workload]
-    pol, disc, agent, ro, loader, expert = build_problem(sg, w, seed=0)
+    pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, seed=0)
     _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
-    rms = sg.RunningMeanStd(shape=())
 
     def barrier():
         ctx.synchronize()
         pg.barrier()
 
     for _ in range(args.warmup):
-        one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+        learner.update()
     barrier()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        last = one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+        last = learner.update()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -207,19 +192,19 @@ def main():
     # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
     ctx.profile_reset()
     ctx.profile(True)
-    one_update(sg, lib, pol, disc, agent, ro, loader, w, rms, world)
+    learner.update()
     ctx.profile(False)
     prof = {name: ctx.profile_read(i) for i, name in enumerate(
-        ["disc_grad", "disc_adam", "ppo_grad", "ppo_reduce", "ppo_adam", "relabel_fwd"])}
+        ["disc_chain", "disc_wgrad", "ppo_grad", "ppo_reduce", "ppo_adam", "relabel_fwd"])}
 
     if rank == 0:
         work = algorithmic_work(w, world)
         env_steps = w["T"] * w["N"] * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = env_steps * args.steps / elapsed
-        dg_ms, dg_n = prof["disc_grad"]
+        dg_ms, dg_n = prof["disc_chain"]
         dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
-        achieved = work["d_step_flops"] / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
+        achieved = work["d_chain_flops"] / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
         name, num_cu, hbm = ctx.device_info()
         out = {
             "metric": "env-steps/sec of GAIL-dyn PPO update", "value": round(value, 1), "unit": "env-steps/s",
@@ -230,10 +215,11 @@ def main():
                                    f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}",
                        "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_disc_grad", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": "k_disc_chain", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
                          "traffic": None, "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
-                         "algorithmic_flops_per_launch": work["d_step_flops"],
+                         "algorithmic_flops_per_launch": work["d_chain_flops"],
+                         "note": "serial chain of 16 workgroups per 128-row step: latency-bound, see DESIGN.md section 4",
                          "whole_update": {"TFLOP/s": round(work["flops"] * args.steps / elapsed / 1e12, 3),
                                           "GB/s": round(work["bytes"] * args.steps / elapsed / 1e9, 2),
                                           "frac_mfma": round(work["flops"] * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
@@ -241,7 +227,7 @@ def main():
             "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()},
             "kernel_launches": {k: v[1] for k, v in prof.items()},
             "us_per_optimizer_step": round(1e3 * ms_per_step / (work["d_steps"] + work["ppo_steps"]), 2),
-            "last_losses": {"disc": last[0], "ppo": last[1]},
+            "last_losses": last,
             "device": name, "num_cu": num_cu,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,100 @@
+"""The GAIL-dyn outer iteration (a2c/main_gail_dyn_ppo.py:201-343, row A12 of SURVEY.md section 8)
+as a reusable driver over the drop-in classes.
+
+The reference mains cannot run unmodified in a current environment (np.infty, whole-module
+torch.load, gym/pybullet), so this module reproduces their per-iteration call sequence:
+
+    [rollout fill]  ->  get_value(obs[-1])  ->  gail_epoch x update_gail_dyn  ->  alive-bonus offset
+    ->  reward relabel + return normalisation  ->  compute_returns  ->  PPO.update  ->  after_update
+
+`GailDynLearner.update()` is the part the metric times (everything after the rollout fill);
+`collect()` fills the rollout from any vectorised environment exposing
+`step(action) -> (obs, reward, done, infos)` with `info["sas_feat"]` rows (the reference builds them
+from info["sas_window"], a2c/main_gail_dyn_ppo.py:220-226).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .utils import RunningMeanStd, to_host_tensor, update_linear_schedule
+
+
+def alive_bonus_offset(num_of_dones, num_steps, num_processes, gail_tar_length, no_alive_bonus=False):
+    """a2c/main_gail_dyn_ppo.py:258-271: r_sa = log d - log(1-d), d = 1 - dones/(dones + T*N/len_e),
+    dones = sum(1-masks) + N/2."""
+    if no_alive_bonus:
+        return 0.0
+    dones = num_of_dones + num_processes / 2
+    num_of_expert_dones = (num_steps * num_processes) / gail_tar_length
+    d_sa = 1 - dones / (dones + num_of_expert_dones)
+    return float(np.log(d_sa) - np.log(1 - d_sa))
+
+
+class ExpertLoader(object):
+    """What the library needs from DataLoader(TensorDataset(expert), batch_size, shuffle=True,
+    drop_last=len>batch) (a2c/main_gail_dyn_ppo.py:165-174): the matrix and the batch size."""
+
+    def __init__(self, expert, batch_size):
+        self.expert = _lib.as_f32(expert)
+        self.batch_size = int(batch_size)
+
+
+class GailDynLearner(object):
+    def __init__(self, actor_critic, agent, discr, rollouts, expert, gail_batch_size=128, gail_epoch=5,
+                 gamma=0.99, gae_lambda=0.95, use_gae=True, use_proper_time_limits=True,
+                 gail_tar_length=500.0, no_alive_bonus=False, use_linear_lr_decay=False, lr=None,
+                 num_updates=None):
+        self.actor_critic, self.agent, self.discr, self.rollouts = actor_critic, agent, discr, rollouts
+        self.loader = expert if hasattr(expert, "batch_size") else ExpertLoader(expert, gail_batch_size)
+        self.gail_epoch, self.gamma, self.gae_lambda = gail_epoch, gamma, gae_lambda
+        self.use_gae, self.use_proper_time_limits = use_gae, use_proper_time_limits
+        self.gail_tar_length, self.no_alive_bonus = gail_tar_length, no_alive_bonus
+        self.use_linear_lr_decay, self.lr, self.num_updates = use_linear_lr_decay, lr, num_updates
+        self.ret_rms = RunningMeanStd(shape=())        # a2c/main_gail_dyn_ppo.py:198-199
+        self.j = 0
+        self.world = getattr(rollouts.ctx, "world", 1)
+
+    # ---------------------------------------------------------------- rollout fill (:209-236)
+    def collect(self, envs, sas_feat_of_infos):
+        ro, pol = self.rollouts, self.actor_critic
+        for step in range(ro.num_steps):
+            value, action, logp, hxs = pol.act(ro.obs[step], ro.recurrent_hidden_states[step], ro.masks[step])
+            obs, reward, done, infos = envs.step(action)
+            masks = np.array([[0.0] if d else [1.0] for d in done], np.float32)
+            bad = np.array([[0.0] if 'bad_transition' in info.keys() else [1.0] for info in infos], np.float32)
+            ro.insert(obs, hxs, action, logp, value, reward, to_host_tensor(masks), to_host_tensor(bad),
+                      to_host_tensor(np.asarray(sas_feat_of_infos(infos), np.float32)))
+        if ro.device_resident:
+            ro.sync_to_device()
+
+    # ------------------------------------------------------------- the timed part (:239-304)
+    def update(self):
+        ro, lib = self.rollouts, self.rollouts.lib
+        if self.use_linear_lr_decay:            # :203-207
+            update_linear_schedule(self.agent.optimizer, self.j, self.num_updates, self.lr)
+        gail = None
+        for _ in range(self.gail_epoch):        # :255-256
+            gail = self.discr.update_gail_dyn(self.loader, ro)
+        if ro.device_resident:
+            dones = C.c_double(0)
+            _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))   # all ranks (RCCL) when world > 1
+            n_dones = dones.value
+        else:
+            m = ro.masks.numpy() if hasattr(ro.masks, "numpy") else ro.masks
+            n_dones = float((1.0 - m).sum())
+        r_sa = alive_bonus_offset(n_dones, ro.num_steps, ro.num_processes * self.world, self.gail_tar_length,
+                                  self.no_alive_bonus)
+        self.discr.relabel_rewards(ro, self.gamma, -r_sa, self.ret_rms)     # :275-297 fused on device
+        if ro.device_resident:
+            _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, self.actor_critic.h, 1 if self.use_gae else 0,
+                                                             float(self.gamma), float(self.gae_lambda),
+                                                             1 if self.use_proper_time_limits else 0))
+        else:
+            next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
+            ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
+        ppo = self.agent.update(ro)             # :302
+        ro.after_update()                       # :304
+        self.j += 1
+        return {"gail_loss": gail[0], "gail_loss_e": gail[1], "gail_loss_p": gail[2], "value_loss": ppo[0],
+                "action_loss": ppo[1], "dist_entropy": ppo[2], "r_sa": r_sa}

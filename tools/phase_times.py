@@ -12,7 +12,7 @@ from simgan_amd import _lib  # noqa: E402
 from bench import WORKLOADS, build_problem  # noqa: E402
 
 w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "northstar"]
-pol, disc, agent, ro, loader, expert = build_problem(sg, w, 0)
+pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, 0)
 lib = _lib.load()
 _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
 fn = lib.sg_test_disc_phase_times
