@@ -142,13 +142,16 @@ struct sg_ppo {
     sg_policy* policy;
     sg_ppo_config cfg;
     float *d_m = nullptr, *d_v = nullptr, *d_grad = nullptr;
-    float* d_slabs = nullptr;      // [n_slabs][total] per-workgroup partial gradients
-    int n_slabs = 0;
+    float* d_slabs = nullptr;      // [row groups][total+8] partial bias-type gradients and loss sums
+    size_t slabs_cap = 0;
+    float* d_stacks = nullptr;     // row stacks of one minibatch (activations / their gradients)
+    size_t stacks_cap = 0;
     float* d_state = nullptr;      // device scalars: see SgOptState
     int64_t* d_perms = nullptr;    // [ppo_epoch][T*N]
     int64_t perms_cap = 0;
     double* d_loss_acc = nullptr;  // [3] running loss sums over the update
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
+    long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
 };
 
 struct sg_disc {

@@ -1,0 +1,317 @@
+// sg_ppo.hip -- PPO.update on gfx950: advantage normalisation, then per optimizer step the
+// clipped-surrogate / clipped-value / entropy loss, its gradient, global-norm clipping and Adam.
+//
+// Replaces (reference, a2c/ = third_party/a2c_ppo_acktr/): PPO.__init__/update a2c/algo/ppo.py:29-157,
+// the minibatch gather of RolloutStorage.feed_forward_generator a2c/storage.py:144-192 and
+// nn.utils.clip_grad_norm_ + optim.Adam (a2c/algo/ppo.py:143-145).  Kernels: sg_ppo_kernels.hpp.
+//
+// Launch sequence of one update (all on the library's stream, one host synchronisation at the end):
+//   k_adv_stats x3                                   advantages, global mean / unbiased std
+//   per epoch:   k_ppo_epoch_gather                  permuted copy of the rollout
+//   per step:    k_ppo_fwd -> k_ppo_bwd -> k_ppo_reduce [-> all-reduce -> k_sumsq] -> k_ppo_adam
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sg_common.h"
+#include "sg_rng.hpp"
+#include "sg_ppo_kernels.hpp"
+
+__global__ void k_fill_perm(int64_t* perm, int64_t n, int half_bits, uint64_t key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = sg_perm_at(i, n, half_bits, key);
+}
+
+int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_t stream_id) {
+    const uint64_t key = sg_key(seed, 0x5045524Dull, stream_id);
+    hipLaunchKernelGGL(k_fill_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_perm, n,
+                       sg_perm_half_bits((uint64_t)n), key);
+    SG_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- launch
+static int max_trunk_floats(const SgPolicyDesc& d) {
+    int m = 0;
+    for (int t = 0; t < d.n_trunks; ++t) m = d.trunk[t].size > m ? d.trunk[t].size : m;
+    return m;
+}
+static int max_bwd_floats(const SgPolicyDesc& d) {
+    int m = 0;
+    for (int t = 0; t < d.n_trunks; ++t) { const int s = d.trunk[t].size - d.trunk[t].w2; m = s > m ? s : m; }
+    return m;
+}
+static int stack_ldP(const SgPolicyDesc& d) {
+    int m = 0;
+    for (int t = 0; t < d.n_trunks; ++t) m = d.trunk[t].ldP > m ? d.trunk[t].ldP : m;
+    return m;
+}
+static size_t ppo_fwd_lds(const SgPolicyDesc& d, int MT) {
+    const int R = 16 * MT;
+    return sizeof(float) * ((size_t)max_trunk_floats(d) + R * d.ldO + 2 * R * d.ldH);
+}
+static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT) {
+    const int R = 16 * MT;
+    return sizeof(float) * ((size_t)max_bwd_floats(d) + R * d.ldO + 2 * R * d.ldH + 2 * R * stack_ldP(d) +
+                            ((R * d.A + 3) & ~3) + 7 * R);
+}
+
+// shape-specialised instances for the shipped configurations at 32-row
+// tiles, plus run-time-shape fallbacks
+#define SG_PPO_SHAPES(X) X(2, 3, 4) /* north-star: obs 47, h64 */ X(2, 1, 7) /* HopperCombined: obs 14, h100 */ \
+                         X(2, 4, 7) /* LaikagoCombined: obs 64, h100 */ X(2, 7, 4) /* Laikago refinement: obs 111, h64 */
+
+static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
+    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const dim3 block(256);
+#define SG_CASE(mt, o, h) \
+    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<mt, o, h>), grid, block, lds, pa); return; }
+    SG_PPO_SHAPES(SG_CASE)
+#undef SG_CASE
+    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<4, 0, 0>), grid, block, lds, pa);
+    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
+}
+static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
+    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const dim3 block(256);
+#define SG_CASE(mt, o, h) \
+    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<mt, o, h>), grid, block, lds, pa); return; }
+    SG_PPO_SHAPES(SG_CASE)
+#undef SG_CASE
+    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<4, 0, 0>), grid, block, lds, pa);
+    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<1, 0, 0>), grid, block, lds, pa);
+}
+
+// ---------------------------------------------------------------------------------- PPO API
+extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg, sg_ppo** out) {
+    SG_REQUIRE(ctx && p && cfg && out, "sg_ppo_create: NULL argument");
+    SG_REQUIRE(cfg->ppo_epoch > 0 && cfg->num_mini_batch > 0, "sg_ppo_create: ppo_epoch and num_mini_batch must be positive");
+    SG_REQUIRE(ppo_fwd_lds(p->desc, 1) <= (size_t)ctx->lds_bytes && ppo_bwd_lds(p->desc, 1) <= (size_t)ctx->lds_bytes,
+               "sg_ppo_create: policy too large for the LDS-resident PPO kernels (%zu / %zu > %d bytes)",
+               ppo_fwd_lds(p->desc, 1), ppo_bwd_lds(p->desc, 1), ctx->lds_bytes);
+    SG_CHECK(hipSetDevice(ctx->device));
+    sg_ppo* a = new sg_ppo();
+    a->ctx = ctx; a->policy = p; a->cfg = *cfg;
+    const size_t tot = (size_t)p->desc.total + 8;
+    SG_CHECK(hipMalloc((void**)&a->d_m, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&a->d_v, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&a->d_grad, sizeof(float) * tot));
+    SG_CHECK(hipMalloc((void**)&a->d_state, sizeof(SgOptState)));
+    SG_CHECK(hipMalloc((void**)&a->d_loss_acc, sizeof(double) * 8));
+    SG_CHECK(hipMalloc((void**)&a->d_part, sizeof(float) * ((tot + 255) / 256 + 8)));
+    SG_CHECK(hipMemsetAsync(a->d_m, 0, sizeof(float) * tot, ctx->stream));
+    SG_CHECK(hipMemsetAsync(a->d_v, 0, sizeof(float) * tot, ctx->stream));
+    SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 8, ctx->stream));
+    SgOptState st;
+    memset(&st, 0, sizeof st);
+    st.lr = cfg->lr;
+    SG_CHECK(hipMemcpyAsync(a->d_state, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = a;
+    return 0;
+}
+
+extern "C" int sg_ppo_destroy(sg_ppo* a) {
+    if (!a) return 0;
+    (void)hipStreamSynchronize(a->ctx->stream);
+    float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks};
+    for (float* q : ptrs) if (q) (void)hipFree(q);
+    if (a->d_perms) (void)hipFree(a->d_perms);
+    if (a->d_loss_acc) (void)hipFree(a->d_loss_acc);
+    if (a->d_dbg) (void)hipFree(a->d_dbg);
+    delete a;
+    return 0;
+}
+
+extern "C" int sg_ppo_set_lr(sg_ppo* a, float lr) {
+    SG_REQUIRE(a, "sg_ppo_set_lr: NULL argument");
+    a->cfg.lr = lr;
+    SG_CHECK(hipMemcpyAsync(&reinterpret_cast<SgOptState*>(a->d_state)->lr, &a->cfg.lr, sizeof(float),
+                            hipMemcpyHostToDevice, a->ctx->stream));
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_ppo_get_adam(sg_ppo* a, float* m, float* v, int64_t n, int64_t* step) {
+    SG_REQUIRE(a && m && v && step, "sg_ppo_get_adam: NULL argument");
+    const SgPolicyDesc& d = a->policy->desc;
+    SG_REQUIRE(n == sg_policy_flat_count(d), "sg_ppo_get_adam: bad length");
+    std::vector<float> pm(d.total), pv(d.total);
+    SgOptState st;
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    SG_CHECK(hipMemcpy(pm.data(), a->d_m, sizeof(float) * d.total, hipMemcpyDeviceToHost));
+    SG_CHECK(hipMemcpy(pv.data(), a->d_v, sizeof(float) * d.total, hipMemcpyDeviceToHost));
+    SG_CHECK(hipMemcpy(&st, a->d_state, sizeof st, hipMemcpyDeviceToHost));
+    sg_policy_unpad(d, pm.data(), m);
+    sg_policy_unpad(d, pv.data(), v);
+    *step = (int64_t)st.step;
+    return 0;
+}
+
+extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_t n, int64_t step) {
+    SG_REQUIRE(a && m && v, "sg_ppo_set_adam: NULL argument");
+    const SgPolicyDesc& d = a->policy->desc;
+    SG_REQUIRE(n == sg_policy_flat_count(d), "sg_ppo_set_adam: bad length");
+    std::vector<float> pm(d.total, 0.f), pv(d.total, 0.f);
+    sg_policy_pad(d, m, pm.data());
+    sg_policy_pad(d, v, pv.data());
+    const float fs = (float)step;
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    SG_CHECK(hipMemcpy(a->d_m, pm.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
+    SG_CHECK(hipMemcpy(a->d_v, pv.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
+    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(a->d_state)->step, &fs, sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uint64_t seed, float out3[3]) {
+    SG_REQUIRE(a && r && out3, "sg_ppo_update: NULL argument");
+    sg_ctx* ctx = a->ctx;
+    const SgPolicyDesc& d = a->policy->desc;
+    SG_REQUIRE(r->O == d.O && r->A == d.A, "sg_ppo_update: rollout dims (obs %d, act %d) do not match the policy (%d, %d)",
+               r->O, r->A, d.O, d.A);
+    const int64_t TN = (int64_t)r->T * r->N;
+    const int M = a->cfg.num_mini_batch, E = a->cfg.ppo_epoch;
+    // a2c/storage.py:152-157
+    SG_REQUIRE(TN >= M, "PPO requires the number of processes (%d) * number of steps (%d) = %lld to be greater than "
+               "or equal to the number of PPO mini batches (%d).", r->N, r->T, (long long)TN, M);
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int mb = (int)(TN / M);
+    const int world = ctx->world;
+
+    // advantages (global mean / unbiased std)
+    float* adv = r->d_field[SG_F_ADVANTAGES];
+    double* stats = a->d_loss_acc + 4;
+    hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(1024), 0, ctx->stream, r->d_field[SG_F_RETURNS],
+                       r->d_field[SG_F_VALUE_PREDS], TN, adv, stats, 0);
+    if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats, 3));       // sum and n are linear
+    hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(1024), 0, ctx->stream, r->d_field[SG_F_RETURNS],
+                       r->d_field[SG_F_VALUE_PREDS], TN, adv, stats, 1);
+    if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats + 1, 1));   // squares about the global mean
+    hipLaunchKernelGGL(k_adv_stats, dim3(64), dim3(1024), 0, ctx->stream, r->d_field[SG_F_RETURNS],
+                       r->d_field[SG_F_VALUE_PREDS], TN, adv, stats, 2);
+    SG_CHECK(hipGetLastError());
+
+    // permutations
+    if (a->perms_cap < (int64_t)E * TN) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (a->d_perms) SG_CHECK(hipFree(a->d_perms));
+        SG_CHECK(hipMalloc((void**)&a->d_perms, sizeof(int64_t) * (size_t)E * TN));
+        a->perms_cap = (int64_t)E * TN;
+    }
+    if (perms) {
+        SG_CHECK(hipMemcpyAsync(a->d_perms, perms, sizeof(int64_t) * (size_t)E * TN, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int e = 0; e < E; ++e)
+            SG_TRY(sg_fill_perm(ctx, a->d_perms + (size_t)e * TN, TN, seed, (uint64_t)e * 2654435761ull + (uint64_t)ctx->rank));
+    }
+
+    // launch geometry: 32-row tiles when that still gives >= half a workgroup per CU, else 16
+    int MT = ((mb + 31) / 32) * d.n_trunks >= ctx->num_cu / 2 ? 2 : 1;
+    if (const char* e = getenv("SG_PPO_ROWS")) {   // tuning knob
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64) MT = v / 16;
+    }
+    while (MT > 1 && (ppo_fwd_lds(d, MT) > (size_t)ctx->lds_bytes || ppo_bwd_lds(d, MT) > (size_t)ctx->lds_bytes)) MT /= 2;
+    const int R = 16 * MT;
+    const int G = (mb + R - 1) / R;
+    const int mbp = G * R;
+    const int ldP = stack_ldP(d);
+    const int slab_stride = d.total + 8;
+    const int TNp = (int)TN + 64;        // slack rows: the last row tile may read past the last minibatch
+
+    // scratch: slabs | epoch copy (X, ACT, SC) | per-trunk row stacks (H1, H2, OUT)
+    const size_t slab_f = (size_t)G * slab_stride;
+    const size_t epoch_f = (size_t)TNp * (d.ldO + d.A + 4);
+    const size_t stack_f = (size_t)d.n_trunks * mbp * (2 * (size_t)d.ldH + ldP);
+    if (a->slabs_cap < slab_f || a->stacks_cap < epoch_f + stack_f) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (a->d_slabs) SG_CHECK(hipFree(a->d_slabs));
+        if (a->d_stacks) SG_CHECK(hipFree(a->d_stacks));
+        SG_CHECK(hipMalloc((void**)&a->d_slabs, sizeof(float) * slab_f));
+        SG_CHECK(hipMalloc((void**)&a->d_stacks, sizeof(float) * (epoch_f + stack_f)));
+        a->slabs_cap = slab_f;
+        a->stacks_cap = epoch_f + stack_f;
+    }
+    // ld-padding columns of the slabs are never written by the kernels and must read as zero; the
+    // epoch copy's slack rows must be finite
+    SG_CHECK(hipMemsetAsync(a->d_slabs, 0, sizeof(float) * slab_f, ctx->stream));
+    SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
+    SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 3, ctx->stream));
+
+    float* epX = a->d_stacks;
+    float* epACT = epX + (size_t)TNp * d.ldO;
+    float* epSC = epACT + (size_t)TNp * d.A;
+    float* stk = epSC + (size_t)TNp * 4;
+
+    EpochGatherArgs ga;
+    ga.obs = r->d_field[SG_F_OBS]; ga.actions = r->d_field[SG_F_ACTIONS]; ga.old_logp = r->d_field[SG_F_LOGP];
+    ga.adv = adv; ga.vpred = r->d_field[SG_F_VALUE_PREDS]; ga.ret = r->d_field[SG_F_RETURNS];
+    ga.TN = TN; ga.O = d.O; ga.Op = d.Op; ga.ldO = d.ldO; ga.A = d.A; ga.sc_stride = TNp;
+    ga.X = epX; ga.ACT = epACT; ga.SC = epSC;
+
+    PpoArgs pa;
+    pa.d = d; pa.params = a->policy->d_params;
+    pa.sc_stride = TNp; pa.mb = mb; pa.mbp = mbp; pa.inv_B = 1.0f / (float)((int64_t)mb * world);
+    pa.clip = a->cfg.clip_param; pa.vcoef = a->cfg.value_loss_coef; pa.ecoef = a->cfg.entropy_coef;
+    pa.use_clipped = a->cfg.use_clipped_value_loss;
+    pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
+    for (int t = 0; t < 3; ++t) {
+        const bool on = t < d.n_trunks;
+        pa.H1[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
+        pa.H2[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
+        pa.OUT[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * ldP;
+    }
+    const int wb_f = max_trunk_floats(d), wb_b = max_bwd_floats(d);
+    const size_t lds_f = ppo_fwd_lds(d, MT), lds_b = ppo_bwd_lds(d, MT);
+    const int nblk = (d.total + 8 + 255) / 256;
+    SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
+
+    for (int e = 0; e < E; ++e) {
+        ga.perm = a->d_perms + (size_t)e * TN;
+        hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
+        for (int k = 0; k < M; ++k) {
+            const size_t rb = (size_t)k * mb;
+            pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
+            pa.wbuf_floats = wb_f;
+            launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
+            pa.wbuf_floats = wb_b;
+            launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa);
+            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
+                      d.total, a->d_grad, a->d_part, st);
+            if (ctx->use_comm) {
+                SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
+                hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
+            }
+            hipLaunchKernelGGL(k_ppo_adam, dim3(nblk), dim3(256), 0, ctx->stream, a->policy->d_params, a->d_m, a->d_v,
+                               a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
+                               a->d_loss_acc);
+        }
+    }
+    SG_CHECK(hipGetLastError());
+    double acc[3];
+    SG_CHECK(hipMemcpyAsync(acc, a->d_loss_acc, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    const double nu = (double)E * M;
+    for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
+    return 0;
+}
+
+// Test hook: per-phase shader-clock timestamps of k_ppo_fwd, row groups [0, n_blocks) (tools/ppo_phase_times.py).
+extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, int n_blocks) {
+    SG_REQUIRE(a, "sg_test_ppo_phase_times: NULL argument");
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    if (enable && !a->d_dbg) {
+        SG_CHECK(hipMalloc((void**)&a->d_dbg, sizeof(long long) * 16 * 1024));
+        SG_CHECK(hipMemset(a->d_dbg, 0, sizeof(long long) * 16 * 1024));
+    }
+    if (out && a->d_dbg) {
+        SG_REQUIRE(n_blocks <= 1024, "sg_test_ppo_phase_times: at most 1024 blocks");
+        SG_CHECK(hipMemcpy(out, a->d_dbg, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost));
+    }
+    if (!enable && a->d_dbg) { SG_CHECK(hipFree(a->d_dbg)); a->d_dbg = nullptr; }
+    return 0;
+}

@@ -1,0 +1,447 @@
+// sg_ppo_kernels.hpp -- device kernels of one PPO optimizer step (a2c/algo/ppo.py:82-145).
+//
+//   k_ppo_epoch_gather    once per epoch: the permuted copy of the rollout the epoch's minibatches
+//                         read (obs rows padded to the LDS stride, actions, per-row scalars), so the
+//                         per-step kernels load contiguous 16-byte-aligned rows instead of chasing
+//                         permutation indices (a2c/storage.py:159-185 gathers per minibatch).
+//   k_ppo_fwd<MT,KO,KH>   grid (row groups, trunks): one trunk's parameter block in LDS, forward on
+//                         R = 16*MT rows; h1, h2 and the head outputs go to global row stacks.
+//   k_ppo_bwd<MT,KO,KH>   grid (row groups, trunks): reload the rows' activations, evaluate the loss
+//                         (needs the head outputs of every actor trunk: the log-prob sums over all
+//                         action dims), back-propagate, form the row group's partial gradient of the
+//                         trunk (three TN GEMMs on the LDS tiles, bias sums from the epilogues) and
+//                         write it to the row group's slab.
+//   k_ppo_reduce          slab sum per parameter (8 loads in flight), per-block sum of squares,
+//                         advance Adam's t.
+//   k_ppo_adam            clip coefficient max_norm/(||g||+1e-6) (<= 1), then Adam.
+// Splitting forward / backward per trunk keeps every workgroup's LDS to one trunk's parameters
+// (the split policy's trunks are 69-98 KB each) and lets all trunks of all row groups run
+// concurrently: 2 x 128 workgroups for Policy, 3 x 128 for SplitPolicy at 4096-row minibatches.
+#pragma once
+#include "sg_common.h"
+
+#define HALF_LOG_2PI 0.91893853320467274178f
+
+struct PpoArgs {
+    SgPolicyDesc d;
+    const float* params;
+    // this minibatch's rows in the epoch's permuted copy
+    const float* X;       // [mb..][ldO]
+    const float* ACT;     // [mb..][A]
+    const float* SC;      // [4][sc_stride]: old_logp | adv | value_pred | return
+    int sc_stride;
+    int mb, mbp;          // local minibatch rows / rounded up to the row tile
+    float inv_B;          // 1 / global minibatch rows
+    float clip, vcoef, ecoef;
+    int use_clipped;
+    float* H1[3];         // [mbp][ldH] per trunk
+    float* H2[3];
+    float* OUT[3];        // [mbp][ldP] head outputs
+    float* slabs;         // [G][total+8] per-row-group partial gradients (+3 loss sums)
+    int slab_stride;
+    int ldP;              // stride of the OUT stacks (max over trunks)
+    int wbuf_floats;
+    long long* dbg;       // optional phase timestamps [block][16] (test hook), NULL in production
+};
+
+#define SG_PPO_STAMP(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[blockIdx.x * 16 + (n)] = clock64(); } while (0)
+
+struct EpochGatherArgs {
+    const float *obs, *actions, *old_logp, *adv, *vpred, *ret;
+    const int64_t* perm;
+    int64_t TN;
+    int O, Op, ldO, A, sc_stride;
+    float *X, *ACT, *SC;
+};
+
+__global__ __launch_bounds__(256) void k_ppo_epoch_gather(EpochGatherArgs a) {
+    __shared__ int IDX[64];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if (tid < 64) {
+        const int64_t rr = row0 + tid;
+        const int idx = rr < a.TN ? (int)a.perm[rr] : -1;
+        IDX[tid] = idx;
+        if (idx >= 0) {
+            a.SC[0 * (size_t)a.sc_stride + rr] = a.old_logp[idx];
+            a.SC[1 * (size_t)a.sc_stride + rr] = a.adv[idx];
+            a.SC[2 * (size_t)a.sc_stride + rr] = a.vpred[idx];
+            a.SC[3 * (size_t)a.sc_stride + rr] = a.ret[idx];
+        }
+    }
+    __syncthreads();
+    for (int base = tid; base < 64 * a.Op; base += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * blockDim.x;
+            const int r = i / a.Op, c = i - r * a.Op;
+            v[u] = (i < 64 * a.Op && IDX[r] >= 0 && c < a.O) ? a.obs[(size_t)IDX[r] * a.O + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * blockDim.x;
+            if (i < 64 * a.Op && IDX[i / a.Op] >= 0) a.X[(size_t)(row0 + i / a.Op) * a.ldO + (i % a.Op)] = v[u];
+        }
+    }
+    for (int i = tid; i < 64 * a.A; i += blockDim.x) {
+        const int r = i / a.A, c = i - r * a.A;
+        if (IDX[r] >= 0) a.ACT[(size_t)(row0 + r) * a.A + c] = a.actions[(size_t)IDX[r] * a.A + c];
+    }
+}
+
+// --------------------------------------------------------------------------------- forward
+template <int MT, int KO, int KH>
+__global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 16 * MT;
+    SgPolicyDesc d = a.d;
+    if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
+    const int t = blockIdx.y, tid = threadIdx.x;
+    const SgTrunk tr = d.trunk[t];
+    const int ldO = d.ldO, ldH = d.ldH, ldP = a.ldP;
+    float* W = smem;
+    float* X = W + a.wbuf_floats;
+    float* H1 = X + R * ldO;
+    float* H2 = H1 + R * ldH;
+    const int row0 = blockIdx.x * R;
+
+    SG_PPO_STAMP(0);
+    float4 wv[12];
+    sg_stage_issue<12>(wv, a.params + tr.off, tr.size / 4);
+    {   // the row tile: contiguous in the epoch's permuted copy
+        const float4* gx = reinterpret_cast<const float4*>(a.X + (size_t)row0 * ldO);
+        float4* lx = reinterpret_cast<float4*>(X);
+        for (int i = tid; i < R * ldO / 4; i += blockDim.x) lx[i] = gx[i];
+    }
+    SG_PPO_STAMP(1);
+    sg_stage_commit<12>(W, wv, a.params + tr.off, tr.size / 4);
+    __syncthreads();
+    SG_PPO_STAMP(2);
+    const float* b1 = W + tr.b1;
+    const float* b2 = W + tr.b2;
+    const float* bh = W + tr.bh;
+    float* gH1 = a.H1[t] + (size_t)row0 * ldH;
+    float* gH2 = a.H2[t] + (size_t)row0 * ldH;
+    float* gOUT = a.OUT[t] + (size_t)row0 * ldP;
+    sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp, [&](int r, int c, float v) {
+        const float h = sg_tanh(v + b1[c]);
+        H1[r * ldH + c] = h;
+        gH1[r * ldH + c] = h;
+    });
+    __syncthreads();
+    SG_PPO_STAMP(3);
+    sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp, [&](int r, int c, float v) {
+        const float h = sg_tanh(v + b2[c]);
+        H2[r * ldH + c] = h;
+        gH2[r * ldH + c] = h;
+    });
+    __syncthreads();
+    SG_PPO_STAMP(4);
+    sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
+    __syncthreads();
+    SG_PPO_STAMP(5);
+}
+
+// -------------------------------------------------------------------------------- backward
+template <int MT, int KO, int KH>
+__global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 16 * MT;
+    SgPolicyDesc d = a.d;
+    if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
+    const int t = blockIdx.y, tid = threadIdx.x;
+    const SgTrunk tr = d.trunk[t];
+    const bool critic = t == d.n_trunks - 1;
+    const bool mlp = d.kind == SG_POLICY_MLP;
+    const int ldO = d.ldO, ldH = d.ldH, ldP = a.ldP, A = d.A;
+    // LDS image of the trunk block from w2 on (w1/b1 are not needed going backward)
+    float* Wimg = smem;
+    const float* W = Wimg - tr.w2;                 // so that W + tr.<off> addresses the block as usual
+    const int wfl = tr.size - tr.w2;
+    float* X = Wimg + a.wbuf_floats;
+    float* H1 = X + R * ldO;
+    float* H2 = H1 + R * ldH;
+    float* O0 = H2 + R * ldH;                      // critic: value head; actors: trunk 0's head outputs
+    float* O1 = O0 + R * ldP;                      // split: trunk 1's head outputs; MLP: per-row d/d logstd
+    float* ACT = O1 + R * ldP;
+    float* SC = ACT + ((R * A + 3) & ~3);          // [4][R]
+    float* ROWL = SC + 4 * R;                      // [2][R]
+    int* VALID = reinterpret_cast<int*>(ROWL + 2 * R);
+    const int row0 = blockIdx.x * R;
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+
+    float4 wv[12];
+    sg_stage_issue<12>(wv, a.params + tr.off + tr.w2, wfl / 4);
+    {   // this row group's inputs, activations and head outputs (contiguous rows)
+        const float4* gx = reinterpret_cast<const float4*>(a.X + (size_t)row0 * ldO);
+        float4* lx = reinterpret_cast<float4*>(X);
+        for (int i = tid; i < R * ldO / 4; i += blockDim.x) lx[i] = gx[i];
+        const float4* g1 = reinterpret_cast<const float4*>(a.H1[t] + (size_t)row0 * ldH);
+        const float4* g2 = reinterpret_cast<const float4*>(a.H2[t] + (size_t)row0 * ldH);
+        float4* l1 = reinterpret_cast<float4*>(H1);
+        float4* l2 = reinterpret_cast<float4*>(H2);
+        for (int i = tid; i < R * ldH / 4; i += blockDim.x) { l1[i] = g1[i]; l2[i] = g2[i]; }
+        const int ta = critic ? t : 0;
+        const float4* go0 = reinterpret_cast<const float4*>(a.OUT[ta] + (size_t)row0 * ldP);
+        float4* lo0 = reinterpret_cast<float4*>(O0);
+        for (int i = tid; i < R * ldP / 4; i += blockDim.x) lo0[i] = go0[i];
+        if (!critic && !mlp) {
+            const float4* go1 = reinterpret_cast<const float4*>(a.OUT[1] + (size_t)row0 * ldP);
+            float4* lo1 = reinterpret_cast<float4*>(O1);
+            for (int i = tid; i < R * ldP / 4; i += blockDim.x) lo1[i] = go1[i];
+        }
+        if (!critic)
+            for (int i = tid; i < R * A; i += blockDim.x) ACT[i] = a.ACT[(size_t)row0 * A + i];
+        if (tid < R) {
+            VALID[tid] = row0 + tid < a.mb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) SC[q * R + tid] = a.SC[(size_t)q * a.sc_stride + row0 + tid];
+        }
+    }
+    sg_stage_commit<12>(Wimg, wv, a.params + tr.off + tr.w2, wfl / 4);
+    __syncthreads();
+
+    // ---- loss and d(loss)/d(head outputs)  (a2c/algo/ppo.py:92-106)
+    if (critic) {
+        if (tid < R) {
+            const int r = tid;
+            const float v = O0[r * ldP];
+            float dv = 0.f, lv = 0.f;
+            if (VALID[r]) {
+                const float Rt = SC[3 * R + r], vo = SC[2 * R + r];
+                if (a.use_clipped) {
+                    const float dvv = v - vo;
+                    const float vc = vo + fminf(fmaxf(dvv, -a.clip), a.clip);
+                    const float u = (v - Rt) * (v - Rt), w = (vc - Rt) * (vc - Rt);
+                    const float m1 = u > w ? 1.f : (u < w ? 0.f : 0.5f);          // torch.max tie -> 1/2, 1/2
+                    const float pass = (dvv >= -a.clip && dvv <= a.clip) ? 1.f : 0.f;
+                    dv = 0.5f * a.inv_B * (m1 * 2.f * (v - Rt) + (1.f - m1) * 2.f * (vc - Rt) * pass);
+                    lv = 0.5f * fmaxf(u, w);
+                } else {
+                    dv = 0.5f * a.inv_B * (-2.f) * (Rt - v);
+                    lv = 0.5f * (Rt - v) * (Rt - v);
+                }
+                dv *= a.vcoef;
+            }
+            O0[r * ldP] = dv;
+            ROWL[r] = lv;
+        }
+    } else {
+        // 32 lanes per row, one action dimension per lane; log-prob / entropy summed across the row's
+        // lanes with shuffles, every lane then forms its own d/dmean, d/dlogstd
+        const SgTrunk tra = d.trunk[0];
+        const int rows_per_pass = blockDim.x >> 5;
+        for (int r = tid >> 5; r < R; r += rows_per_pass) {
+            float* o0 = O0 + r * ldP;
+            float* o1 = O1 + r * ldP;
+            float logp = 0.f, ent = 0.f;
+            for (int k0 = 0; k0 < A; k0 += 32) {       // A <= 32 for every shipped policy: one trip
+                const int k = k0 + (tid & 31);
+                float lp = 0.f, en = 0.f;
+                if (k < A) {
+                    float mean, ls;
+                    if (mlp) { mean = o0[k]; ls = W[tra.ex + k]; }
+                    else if (k < d.nc) { mean = o0[k]; ls = o0[d.nc + k]; }
+                    else { mean = o1[k - d.nc]; ls = o1[d.na + k - d.nc]; }
+                    const float sigma = expf(ls), diff = ACT[r * A + k] - mean, lsig = logf(sigma);
+                    lp = -(diff * diff) / (2.f * sigma * sigma) - lsig - HALF_LOG_2PI;
+                    en = 0.5f + HALF_LOG_2PI + lsig;
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); }
+                logp += lp;
+                ent += en;
+            }
+            const bool valid = VALID[r];
+            float dlogp = 0.f, la = 0.f;
+            if (valid) {
+                const float adv = SC[1 * R + r];
+                const float ratio = expf(logp - SC[0 * R + r]);
+                const float surr1 = ratio * adv;
+                const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
+                const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);  // torch.min tie -> 1/2, 1/2
+                const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
+                dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
+                la = -fminf(surr1, surr2);
+            }
+            const float dent = valid ? a.ecoef * a.inv_B : 0.f;
+            for (int k0 = 0; k0 < A; k0 += 32) {
+                const int k = k0 + (tid & 31);
+                if (k < A) {
+                    float mean, ls, *pm, *pl;
+                    if (mlp) { mean = o0[k]; ls = W[tra.ex + k]; pm = o0 + k; pl = o1 + k; }
+                    else if (k < d.nc) { pm = o0 + k; pl = o0 + d.nc + k; mean = *pm; ls = *pl; }
+                    else { pm = o1 + (k - d.nc); pl = o1 + (d.na + k - d.nc); mean = *pm; ls = *pl; }
+                    const float sigma = expf(ls), var = sigma * sigma, diff = ACT[r * A + k] - mean;
+                    *pm = dlogp * diff / var;
+                    *pl = dlogp * (diff * diff / var - 1.f) - dent;
+                } else if (mlp && k < tra.Pp) {
+                    o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
+                }
+            }
+            if ((tid & 31) == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
+        }
+    }
+    __syncthreads();
+    float* dout = (critic || t == 0) ? O0 : O1;     // this trunk's d loss / d head outputs
+    // loss sums of this row group (recorded once: by the critic and by actor trunk 0)
+    if (tid == 0 && (critic || t == 0)) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < R; ++r) { s0 += ROWL[r]; s1 += ROWL[R + r]; }
+        float* ls = slab + d.total;
+        if (critic) ls[0] = s0;
+        else { ls[1] = s0; ls[2] = s1; }
+    }
+    float* g = slab + tr.off;
+    // head weight / bias gradients (needs h2 before it is overwritten)
+    sg_grad_tn<MT>(dout, ldP, H2, ldH, tr.Pp, d.Hp, g + tr.wh, ldH, false);
+    sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
+    if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
+    __syncthreads();
+    // dZ = (dY W) * (1 - h^2) in place over h; the bias gradient falls out of the epilogue registers
+    auto dz_epilogue = [&](float* h, float* gb) {
+        return [=](int tn, f32x4 (&acc)[MT][1]) {
+            const int c = tn * 16 + (tid & 15), lq = (tid & 63) >> 4;
+            float z[MT][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* ph = h + (i * 16 + 4 * lq + r) * ldH + c;
+                    const float hv = *ph;
+                    z[i][r] = acc[i][0][r] * (1.f - hv * hv);
+                    *ph = z[i][r];
+                }
+            const float sb = sg_tile_colsum<MT>(z);
+            if (lq == 0) gb[c] = sb;
+        };
+    };
+    sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, d.Hp, dz_epilogue(H2, g + tr.b2));
+    __syncthreads();
+    sg_grad_tn<MT>(H2, ldH, H1, ldH, d.Hp, d.Hp, g + tr.w2, ldH, false);
+    __syncthreads();
+    sg_layer_nn_t<MT>(H2, ldH, W + tr.w2, ldH, d.Hp, d.Hp, dz_epilogue(H1, g + tr.b1));
+    __syncthreads();
+    sg_grad_tn<MT>(H1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, false);
+}
+
+// grad[i] = sum over slabs; part[block] = sum of squares of this block's grads; bumps Adam's t.
+__global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_slabs, int slab_stride, int total,
+                                                    float* grad, float* part, SgOptState* st) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float g = 0.f;
+    if (i < total + 8) {
+        // 8 independent partial sums keep 8 slab loads in flight; combined in a fixed order
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= n_slabs; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(s + u) * slab_stride + i];
+        }
+        for (; s < n_slabs; ++s) p[0] += slabs[(size_t)s * slab_stride + i];
+        g = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        grad[i] = g;
+    }
+    float sq = (i < total) ? g * g : 0.f;
+    sq = sg_wave_sum(sq);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+        if (blockIdx.x == 0) sg_opt_advance(st);
+    }
+}
+
+// sum of squares only (data-parallel mode: recomputed after the all-reduce)
+__global__ __launch_bounds__(256) void k_sumsq(const float* grad, int total, float* part) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = (i < total) ? grad[i] * grad[i] : 0.f;
+    sq = sg_wave_sum(sq);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// clip_grad_norm_ + Adam (a2c/algo/ppo.py:143-145; torch.optim.Adam single-tensor math).
+__global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float* v, const float* grad,
+                                                  const float* part, int n_part, int total,
+                                                  const SgOptState* st, float eps, float max_norm,
+                                                  float inv_mb, double* loss_acc) {
+    __shared__ float s_coef;
+    const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int j = threadIdx.x; j < n_part; j += 64) s += part[j];
+        s = sg_wave_sum(s);
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf(s);
+            float coef = max_norm / (norm + 1e-6f);
+            s_coef = coef > 1.f ? 1.f : coef;
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const float g = grad[i] * s_coef;
+        float mi = m[i], vi = v[i];
+        mi = mi + (g - mi) * (float)(1.0 - 0.9);
+        vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
+        const float denom = sqrtf(vi) / s_bc2_sqrt + eps;
+        params[i] = params[i] - s_step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3)  // value_loss.item() etc. are float32, summed in Python doubles
+        loss_acc[threadIdx.x] += (double)(grad[total + threadIdx.x] * inv_mb);
+}
+
+// adv = returns[:-1] - value_preds[:-1]; sums for mean / unbiased std (a2c/algo/ppo.py:66-68)
+__global__ __launch_bounds__(1024) void k_adv_stats(const float* ret, const float* vpred, int64_t n, float* adv,
+                                                    double* stats /* [0]=sum, [1]=sumsq-about-mean, [2]=n */,
+                                                    int pass) {
+    __shared__ double ws[16];
+    __shared__ double s_mean;
+    const int tid = threadIdx.x;
+    if (pass == 0) {
+        double s = 0.0;
+        for (int64_t i = tid; i < n; i += blockDim.x) {
+            const float a = ret[i] - vpred[i];
+            adv[i] = a;
+            s += (double)a;
+        }
+        s = sg_wave_sum(s);
+        if ((tid & 63) == 0) ws[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
+            stats[0] = t;
+            stats[2] = (double)n;
+        }
+    } else if (pass == 1) {
+        if (tid == 0) s_mean = (double)(float)(stats[0] / stats[2]);
+        __syncthreads();
+        const double mean = s_mean;
+        double s = 0.0;
+        for (int64_t i = tid; i < n; i += blockDim.x) {
+            const double dd = (double)adv[i] - mean;
+            s += dd * dd;
+        }
+        s = sg_wave_sum(s);
+        if ((tid & 63) == 0) ws[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
+            stats[1] = t;
+        }
+    } else {
+        const float mean = (float)(stats[0] / stats[2]);
+        const float sd = (float)sqrt(stats[1] / (stats[2] - 1.0));
+        for (int64_t i = tid + (int64_t)blockIdx.x * blockDim.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            adv[i] = (adv[i] - mean) / (sd + 1e-5f);
+    }
+}

@@ -1,0 +1,35 @@
+"""Per-phase shader-clock breakdown of k_ppo_fwd (test hook sg_test_ppo_phase_times).
+Run on the GPU box:  python tools/ppo_phase_times.py [workload]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import simgan_amd as sg  # noqa: E402
+from simgan_amd import _lib  # noqa: E402
+from bench import WORKLOADS, build_problem  # noqa: E402
+
+w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "northstar"]
+pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, 0)
+lib = _lib.load()
+_lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
+_lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, 0.99, 0.95, 1))
+fn = lib.sg_test_ppo_phase_times
+fn.restype = C.c_int
+fn.argtypes = [_lib.H, C.c_int, C.POINTER(C.c_longlong), C.c_int]
+agent.update(ro)
+_lib.check(fn(agent.h, 1, None, 0))
+agent.update(ro)
+nb = 64
+buf = (C.c_longlong * (16 * nb))()
+_lib.check(fn(agent.h, 1, buf, nb))
+t = np.array(buf, dtype=np.int64).reshape(nb, 16)
+names = ["issue+rows", "commit+sync", "L1", "L2", "head"]
+d = np.diff(t[:, :6], axis=1)
+print("k_ppo_fwd phases, median cycles over", nb, "row groups:")
+for i, n in enumerate(names):
+    print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
+print("   total       ", int(np.median(t[:, 5] - t[:, 0])))
+_lib.check(fn(agent.h, 0, None, 0))
