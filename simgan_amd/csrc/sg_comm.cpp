@@ -91,6 +91,8 @@ extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, in
     // they are the identity): the 1-GPU self-test of the RCCL path (tests/test_gpu_comm.py)
     const char* always = getenv("SG_COMM_ALWAYS");
     ctx->use_comm = world > 1 || (always && always[0] == '1');
+    const char* dp = getenv("SG_DISC_DP");
+    ctx->disc_sharded = dp && strcmp(dp, "sharded") == 0;
     return 0;
 }
 

@@ -95,6 +95,7 @@ struct sg_ctx {
     std::vector<hipEvent_t> event_pool;
     SgComm* comm = nullptr;
     int rank = 0, world = 1;
+    bool disc_sharded = false;    // SG_DISC_DP=sharded: all-reduce D gradients per step instead of replicating D
     bool use_comm = false;        // issue the data-parallel collectives (world > 1, or forced for a 1-rank self-test)
     // scratch
     float* d_scratch = nullptr;   // generic device scratch (host<->device staging for API calls)
@@ -167,6 +168,8 @@ struct sg_disc {
     int64_t eperm_cap = 0, pperm_cap = 0;
     float* d_alpha = nullptr;
     int64_t alpha_cap = 0;
+    float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
+    int64_t feat_all_cap = 0;
     double* d_loss_acc = nullptr;
     float* d_returns = nullptr;    // Discriminator.returns [n]
     int returns_n = 0;

@@ -195,7 +195,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
-    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns};
+    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
@@ -285,20 +285,36 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     SG_REQUIRE(d->d_expert, "sg_disc_update_gail_dyn: no expert data (call sg_disc_set_expert first)");
     SG_REQUIRE(r->F == dd.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, dd.F);
     SG_REQUIRE(batch_size > 0, "sg_disc_update_gail_dyn: batch_size must be positive");
+    // Data-parallel modes (world > 1).  "replicated" (default): the discriminator is replicated; once
+    // per call the ranks all-gather their next_obs_feat rows, then every rank runs the SAME sequence of
+    // full-batch steps on the global row set (same seeds, deterministic kernels => identical replicas),
+    // with no per-step collective.  "sharded" (SG_DISC_DP=sharded): each rank takes batch/world rows of
+    // every step and the gradient is all-reduced per step (tests/test_dp_design.py).  Both reproduce the
+    // reference at num_processes = world * N; replicated avoids 2,560+ latency-bound 100 KB all-reduces.
     const int world = ctx->world;
-    SG_REQUIRE(batch_size % world == 0, "sg_disc_update_gail_dyn: batch_size %d must divide by world size %d", batch_size, world);
-    const int B_loc = batch_size / world;
+    const bool replicated = ctx->use_comm && !ctx->disc_sharded;
+    const bool sharded = ctx->use_comm && ctx->disc_sharded;
+    const int split = sharded ? world : 1;
+    SG_REQUIRE(batch_size % split == 0, "sg_disc_update_gail_dyn: batch_size %d must divide by world size %d", batch_size, world);
+    const int B_loc = batch_size / split;
     // the reference's alpha*expert + (1-alpha)*policy raises on a size mismatch when the loader
     // yields a short batch (a2c/algo/gail.py:75)
     SG_REQUIRE(d->n_expert >= batch_size, "The size of tensor a (%lld) must match the size of tensor b (%d) at "
                "non-singleton dimension 0 (expert rows < gail batch size)", (long long)d->n_expert, batch_size);
     SG_CHECK(hipSetDevice(ctx->device));
-    const int64_t TN = (int64_t)r->T * r->N;
+    const int64_t TN_loc = (int64_t)r->T * r->N;
+    const int64_t TN = replicated ? TN_loc * world : TN_loc;     // rows the policy permutation ranges over
     const int64_t n_e = d->n_expert / batch_size;   // drop_last (or exactly one full batch)
-    const int64_t n_p = TN / B_loc;                 // local rows contribute batch/world per step
+    const int64_t n_p = TN / B_loc;                 // sharded: local rows contribute batch/world per step
     const int n_d = (int)(n_e < n_p ? n_e : n_p);
     SG_REQUIRE(n_d > 0, "sg_disc_update_gail_dyn: rollout (%lld rows) smaller than one batch (%d)", (long long)TN, B_loc);
     if (n_steps) *n_steps = n_d;
+    const float* next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
+    if (replicated) {
+        SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * r->F, ctx->stream));
+        SG_TRY(sg_comm_allgather_f32(ctx, next_feat, d->d_feat_all, TN_loc * r->F));
+        next_feat = d->d_feat_all;
+    }
 
     SG_TRY(ensure_cap(&d->d_eperm, &d->eperm_cap, d->n_expert, ctx->stream));
     SG_TRY(ensure_cap(&d->d_pperm, &d->pperm_cap, TN, ctx->stream));
@@ -308,7 +324,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
     else SG_TRY(sg_fill_perm(ctx, d->d_eperm, d->n_expert, seed, 0xE0000000ull + d->rng_calls));
     if (policy_perm) SG_CHECK(hipMemcpyAsync(d->d_pperm, policy_perm, sizeof(int64_t) * TN, hipMemcpyHostToDevice, ctx->stream));
-    else SG_TRY(sg_fill_perm(ctx, d->d_pperm, TN, seed, 0xF0000000ull + d->rng_calls * 1024 + (uint64_t)ctx->rank));
+    else SG_TRY(sg_fill_perm(ctx, d->d_pperm, TN, seed, 0xF0000000ull + d->rng_calls * 1024 + (uint64_t)(sharded ? ctx->rank : 0)));
     if (alpha) SG_CHECK(hipMemcpyAsync(d->d_alpha, alpha, sizeof(float) * (size_t)n_d * batch_size, hipMemcpyHostToDevice, ctx->stream));
     else {
         const int64_t na = (int64_t)n_d * batch_size;
@@ -331,7 +347,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
 
     DiscArgs a;
     a.d = dd; a.params = d->d_params; a.expert = d->d_expert;
-    a.next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
+    a.next_feat = next_feat;
     a.B = B_loc; a.G = G; a.inv_B = 1.0f / (float)batch_size; a.lambda_ = 10.0f;
     // the operand stacks are double-buffered by step parity: while k_disc_wgrad of step k reads
     // stacks[k&1], its spare workgroups gather step k+1's input rows into stacks[(k+1)&1]
@@ -341,15 +357,16 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     float* grad = d->d_slabs + 2 * ops_f + part_f;
     WgradArgs wa;
     wa.d = dd; wa.part = a.part; wa.G = G; wa.params = d->d_params; wa.m = d->d_m; wa.v = d->d_v;
-    wa.grad_out = ctx->use_comm ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
+    wa.grad_out = sharded ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
     wa.loss_acc = d->d_loss_acc;
     const size_t lds = disc_chain_lds_bytes(dd);
     const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
     for (int k = 0; k < n_d; ++k) {
         // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
-        a.eperm = d->d_eperm + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
-        a.alpha = d->d_alpha + (size_t)k * batch_size + (size_t)ctx->rank * B_loc;
+        const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
+        a.eperm = d->d_eperm + (size_t)k * batch_size + roff;
+        a.alpha = d->d_alpha + (size_t)k * batch_size + roff;
         a.pperm = d->d_pperm + (size_t)k * B_loc;
         a.ops = stacks[k & 1];
         wa.ops = a.ops;
@@ -365,7 +382,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
         wa.next = pg;
         launch_disc_chain(ctx, dd, dim3(2 * G), lds, a);
         SG_LAUNCH(ctx, SG_PROF_DISC_ADAM, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
-        if (ctx->use_comm) {
+        if (sharded) {
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
             hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
                                dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc);

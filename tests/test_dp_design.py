@@ -155,9 +155,25 @@ def worker(rank, port, out):
     all_rewards = [None] * WORLD
     dist.all_gather_object(all_rewards, rewards)
 
+    # ---------------- replicated-D mode (the library's default for world > 1): all-gather the ranks'
+    # next_obs_feat rows once, then every rank runs the same full-batch steps on the global row set
+    feats = [None] * WORLD
+    dist.all_gather_object(feats, np.ascontiguousarray(loc["obs_feat"][1:].reshape(-1, F)))
+    feat_all = np.concatenate(feats, axis=0)                       # [world*TN_loc, F], rank-major
+    rng_r = np.random.default_rng(77)                              # same seed on every rank
+    pperm_r = rng_r.permutation(WORLD * tn_loc).astype(np.int64)
+    dpar_r, dadam_r = g["dpar"].copy(), orc.AdamState(g["dpar"].size)
+    n_d_r = min(g["expert"].shape[0] // B, WORLD * tn_loc // B)
+    for k in range(n_d_r):
+        sl = slice(k * B, (k + 1) * B)
+        G, _ = orc.disc_grad_rows(F, HD, dpar_r, g["expert"][g["d_eperm"][sl]], feat_all[pperm_r[sl]], g["alpha"][sl], 1.0 / B)
+        orc.adam_step(dpar_r, G, dadam_r, 1e-3, 1e-8)
+    all_dpar_r = [None] * WORLD
+    dist.all_gather_object(all_dpar_r, dpar_r)
+
     if rank == 0:
         out.update(pi=pi, ppo_losses=ppo_losses, dpar=dpar, d_losses=d_losses, n_d=n_d,
-                   rewards=np.concatenate(all_rewards, axis=1), rms=rms)
+                   rewards=np.concatenate(all_rewards, axis=1), rms=rms, dpar_repl=all_dpar_r, pperm_repl=pperm_r)
     pg.shutdown()
 
 
@@ -223,3 +239,20 @@ def test_relabel_sharded_equals_single_process(dp):
     rewards, _, rms = orc.relabel(F, HD, dp["dpar"], g["obs_feat"], g["masks"], 0.99, -0.3, None, [0.0, 1.0, 1e-4])
     assert_close(dp["rewards"], rewards, rtol=1e-5, what="DP relabelled rewards")
     assert_close(dp["rms"], rms, rtol=1e-6, what="DP ret_rms")
+
+
+def test_disc_update_replicated_equals_single_process(dp):
+    """Replicated-D mode: replicas stay bit-identical across ranks and equal the single-process update
+    on the concatenated rollout (row ids mapped rank-major -> (t, n) of the world-size rollout)."""
+    from oracle import oracle as orc
+    from helpers import assert_close
+    g = make_global()
+    tn_loc = T * N_LOC
+    for other in dp["dpar_repl"][1:]:
+        assert np.array_equal(dp["dpar_repl"][0], other), "replicas diverged"
+    # rank-major global index j = rank*TN_loc + local_row  ->  flattened (t, n_global) row of the full rollout
+    j = dp["pperm_repl"]
+    pperm = to_global_rows(j % tn_loc, j // tn_loc)
+    dpar, adam = g["dpar"].copy(), orc.AdamState(g["dpar"].size)
+    orc.disc_update(F, HD, dpar, adam, g["expert"], g["obs_feat"], B, g["d_eperm"], pperm, g["alpha"])
+    assert_close(dp["dpar_repl"][0], dpar, rtol=1e-6, atol=1e-7, what="replicated D params")

@@ -52,7 +52,9 @@ print("COMM-PATH-OK")
 '''
 
 
-def test_rccl_path_single_rank():
-    env = dict(os.environ, SG_COMM_ALWAYS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("disc_mode", ["replicated", "sharded"])
+def test_rccl_path_single_rank(disc_mode):
+    """replicated: all-gather of next_obs_feat + local D steps; sharded: per-step gradient all-reduce."""
+    env = dict(os.environ, SG_COMM_ALWAYS="1", SG_DISC_DP=disc_mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "COMM-PATH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
