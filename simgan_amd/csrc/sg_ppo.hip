@@ -315,3 +315,28 @@ extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, in
     if (!enable && a->d_dbg) { SG_CHECK(hipFree(a->d_dbg)); a->d_dbg = nullptr; }
     return 0;
 }
+
+// Test hook: the library's counter-based generators as host arrays (tests/test_gpu_fullsize.py).
+// kind 0: random permutation of [0, n) -> int64 out;  1: uniform [0,1) -> float out;  2: normal -> float out.
+__global__ void k_test_rng(float* out, int64_t n, uint64_t seed, int kind) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = kind == 1 ? sg_uniform(seed, 7, (uint64_t)i) : sg_normal(seed, 7, (uint64_t)i);
+}
+
+extern "C" int sg_test_rng(sg_ctx* ctx, int kind, int64_t n, uint64_t seed, void* out) {
+    SG_REQUIRE(ctx && out && n > 0 && kind >= 0 && kind <= 2, "sg_test_rng: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    void* dev = nullptr;
+    SG_CHECK(hipMalloc(&dev, (size_t)n * 8));
+    if (kind == 0) {
+        SG_TRY(sg_fill_perm(ctx, (int64_t*)dev, n, seed, 3));
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        SG_CHECK(hipMemcpy(out, dev, (size_t)n * 8, hipMemcpyDeviceToHost));
+    } else {
+        hipLaunchKernelGGL(k_test_rng, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)dev, n, seed, kind);
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        SG_CHECK(hipMemcpy(out, dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dev);
+    return 0;
+}
