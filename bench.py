@@ -195,7 +195,7 @@ def main():
     learner.update()
     ctx.profile(False)
     prof = {name: ctx.profile_read(i) for i, name in enumerate(
-        ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd"])}
+        ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam"])}
 
     if rank == 0:
         work = algorithmic_work(w, world)

@@ -159,6 +159,14 @@ int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
 int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm,
                             const int64_t *policy_perm, const float *alpha, uint64_t seed,
                             float out3[3], int *n_steps);
+/* Discriminator.update(expert_loader, rollouts, obsfilt, is_gail_dyn, a_dim) a2c/algo/gail.py:91-152, one
+ * epoch: the same step on caller-assembled policy rows [n_rows, input_dim] (host): (state | action)
+ * rows for classic GAIL, (obs_feat | action | next_obs_feat) for is_gail_dyn (a2c/algo/gail.py:102-109).
+ * The expert matrix (sg_disc_set_expert) is assembled the same way.  Other arguments as above;
+ * policy_perm ranges over n_rows. */
+int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, int batch_size,
+                        const int64_t *expert_perm, const int64_t *policy_perm, const float *alpha,
+                        uint64_t seed, float out3[3], int *n_steps);
 /* Discriminator.predict_reward_combined(d_in, gamma, masks, offset) a2c/algo/gail.py:201-210.
  * x[n,F], masks[n] -> reward[n], returns[n]; Discriminator.returns persists inside the handle
  * (first call: returns = reward).  n must stay the same across calls. */
@@ -179,9 +187,10 @@ int sg_rollout_count_dones(sg_rollout *r, double *dones);
 
 /* ------------------------------------------------------------- measurement */
 /* HIP-event timing of the dominant kernels on the library's stream since the last reset:
- * which = 0 discriminator gradient kernel, 1 discriminator reduce+Adam, 2 PPO gradient kernel,
- * 3 PPO reduce, 4 PPO clip+Adam, 5 relabel forward.  Enabled by sg_ctx_profile(ctx, 1); adds
- * event records around every launch (do not enable inside the timed bench region). */
+ * which = 0 k_disc_chain (discriminator step, serial part), 1 k_disc_wgrad (weight gradients + Adam),
+ * 2 k_ppo_fwd, 3 k_ppo_bwd, 4 k_ppo_reduce, 5 relabel forward, 6 k_ppo_adam (clip + Adam).
+ * Enabled by sg_ctx_profile(ctx, 1); adds start/stop events to every launch (do not enable inside
+ * the timed bench region). */
 int sg_ctx_profile(sg_ctx *ctx, int enable);
 int sg_ctx_profile_read(sg_ctx *ctx, int which, double *total_ms, int64_t *launches);
 int sg_ctx_profile_reset(sg_ctx *ctx);

@@ -23,7 +23,7 @@ H = C.c_void_p  # opaque handle
 F_OBS, F_OBS_FEAT, F_ACTIONS, F_REWARDS, F_VALUE_PREDS, F_RETURNS, F_LOGP, F_MASKS, F_BAD_MASKS, \
     F_ADVANTAGES = range(10)
 POLICY_MLP, POLICY_SPLIT = 0, 1
-PROF_DISC_GRAD, PROF_DISC_ADAM, PROF_PPO_GRAD, PROF_PPO_REDUCE, PROF_PPO_ADAM, PROF_RELABEL = range(6)
+PROF_DISC_CHAIN, PROF_DISC_WGRAD, PROF_PPO_FWD, PROF_PPO_BWD, PROF_PPO_REDUCE, PROF_RELABEL, PROF_PPO_ADAM = range(7)
 
 
 class PPOConfig(C.Structure):
@@ -78,6 +78,7 @@ PROTOTYPES = {
     "sg_disc_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
     "sg_disc_set_expert": (C.c_int, [H, c_float_p, C.c_int64]),
     "sg_disc_update_gail_dyn": (C.c_int, [H, H, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
+    "sg_disc_update_rows": (C.c_int, [H, c_float_p, C.c_int64, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
     "sg_disc_reset_returns": (C.c_int, [H]),
     "sg_disc_get_returns": (C.c_int, [H, c_float_p, C.c_int, c_int_p]),

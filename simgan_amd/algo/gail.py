@@ -134,10 +134,42 @@ class Discriminator(object):
         self.last_n_steps = nst.value
         return float(out[0]), float(out[1]), float(out[2])
 
-    def update(self, expert_loader, rollouts, obsfilt=None, is_gail_dyn=False, a_dim=None):
-        """a2c/algo/gail.py:91-152 (state/action GAIL): not called by any shipped driver
-        (a2c/main_gail_dyn_ppo.py:256 uses update_gail_dyn)."""
-        raise NotImplementedError("only the GAIL-dyn update (update_gail_dyn) is on the hot path")
+    def update(self, expert_loader, rollouts, obsfilt=None, is_gail_dyn=False, a_dim=None,
+               expert_perm=None, policy_perm=None, alpha=None):
+        """a2c/algo/gail.py:91-152 (state/action GAIL and its is_gail_dyn feature assembly), one epoch.
+        Not called by any shipped driver (a2c/main_gail_dyn_ppo.py:256 uses update_gail_dyn); same device
+        step on rows assembled here: policy rows = (state | action), or for is_gail_dyn
+        (obs_feat | obs[:, -a_dim:] | next_obs_feat) (a2c/algo/gail.py:102-109)."""
+        ds = expert_loader.dataset
+        key = ("update", id(ds), id(obsfilt))
+        if key != self._expert_id:
+            es, ea = _lib.as_f32(ds.tensors[0]), _lib.as_f32(ds.tensors[1])
+            if obsfilt is not None:
+                es = np.asarray(obsfilt(es, update=False), np.float32)
+            self.set_expert(np.concatenate([es, ea], axis=1))
+            self._expert_id = key
+        B = int(expert_loader.batch_size)
+        npv = lambda t: (t.numpy() if hasattr(t, "numpy") else np.asarray(t))  # noqa: E731
+        obs, acts, feat = npv(rollouts.obs), npv(rollouts.actions), npv(rollouts.obs_feat)
+        flat = lambda a: a.reshape(-1, a.shape[-1])  # noqa: E731
+        if not is_gail_dyn:
+            rows = np.concatenate([flat(obs[:-1]), flat(acts)], axis=1)
+        else:
+            rows = np.concatenate([flat(feat[:-1]), flat(obs[:-1])[:, -a_dim:], flat(feat[1:])], axis=1)
+        rows = np.ascontiguousarray(rows, np.float32)
+        assert rows.shape[1] == self.input_dim, (rows.shape, self.input_dim)
+        out = (C.c_float * 3)()
+        nst = C.c_int(0)
+        ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
+        pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
+        al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
+        self._calls += 1
+        _lib.check(self.lib.sg_disc_update_rows(
+            self.h, _lib.fptr(rows), rows.shape[0], B, None if ep is None else _lib.i64ptr(ep),
+            None if pp is None else _lib.i64ptr(pp), None if al is None else _lib.fptr(al), self.seed + self._calls,
+            out, C.byref(nst)))
+        self.last_n_steps = nst.value
+        return float(out[0]), float(out[1]), float(out[2])
 
     # ---------------------------------------------------------------------- rewards
     def predict_reward_combined(self, d_in, gamma, masks, offset=0.0):

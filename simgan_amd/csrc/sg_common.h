@@ -74,8 +74,8 @@ void sg_disc_pad(const SgDiscDesc& d, const float* flat, float* padded);
 void sg_disc_unpad(const SgDiscDesc& d, const float* padded, float* flat);
 
 // ------------------------------------------------------------------------------------ handles
-enum { SG_PROF_DISC_GRAD = 0, SG_PROF_DISC_ADAM, SG_PROF_PPO_GRAD, SG_PROF_PPO_REDUCE,
-       SG_PROF_PPO_ADAM, SG_PROF_RELABEL, SG_PROF_COUNT };
+enum { SG_PROF_DISC_CHAIN = 0, SG_PROF_DISC_WGRAD, SG_PROF_PPO_FWD, SG_PROF_PPO_BWD,
+       SG_PROF_PPO_REDUCE, SG_PROF_RELABEL, SG_PROF_PPO_ADAM, SG_PROF_COUNT };
 
 struct SgProfSlot {
     double total_ms = 0.0;
@@ -170,6 +170,8 @@ struct sg_disc {
     int64_t alpha_cap = 0;
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
+    float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
+    int64_t rows_cap = 0;
     double* d_loss_acc = nullptr;
     float* d_returns = nullptr;    // Discriminator.returns [n]
     int returns_n = 0;

@@ -14,9 +14,12 @@
 //                 rows through forward/BCE/backward; workgroups [G,2G) take the 16 matching mixup
 //                 rows through forward, input-gradient, penalty and the double backward.  The whole
 //                 parameter vector (its HBM image is the LDS image) is staged once per workgroup;
-//                 every contraction is an LDS-tile fp32 MFMA GEMM; partial gradients go to a
-//                 per-workgroup slab.
-//   k_disc_adam   sums the slabs per parameter and applies Adam (no clipping for D).
+//                 every contraction is an LDS-tile fp32 MFMA GEMM.  It writes the left/right factors
+//                 of every weight-gradient outer product ("operand stacks", 512 stacked rows per
+//                 layer) plus per-workgroup bias / loss partials.
+//   k_disc_wgrad  one workgroup per 16x16 weight tile: TN GEMM over the stacked rows + Adam in place
+//                 (no clipping for D); one block for biases, loss sums and the optimizer scalars;
+//                 2*G blocks gather the NEXT step's rows into the other parity's operand stack.
 //
 // Gradient-penalty math (x = mixup row, s_i = 1 - h_i^2, lambda = 10, B = batch):
 //   d2 = w3*s2; u1 = W2^T d2; d1 = u1*s1; g = W1^T d1; n = |g|; gb = lambda*(2/B)*(n-1)/n * g
@@ -40,10 +43,10 @@ int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_
 static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     const dim3 block(SG_DISC_THREADS);
-    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<6, 7>), grid, block, lds, a);
-    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<2, 7>), grid, block, lds, a);
-    else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<1, 1>), grid, block, lds, a);
-    else SG_LAUNCH(ctx, SG_PROF_DISC_GRAD, (k_disc_chain<0, 0>), grid, block, lds, a);
+    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<6, 7>), grid, block, lds, a);
+    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<2, 7>), grid, block, lds, a);
+    else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<1, 1>), grid, block, lds, a);
+    else SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<0, 0>), grid, block, lds, a);
 }
 
 __global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
@@ -195,7 +198,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
-    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all};
+    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
@@ -276,14 +279,14 @@ static int ensure_cap(T** ptr, int64_t* cap, int64_t need, hipStream_t stream) {
     return 0;
 }
 
-extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm,
-                                       const int64_t* policy_perm, const float* alpha, uint64_t seed,
-                                       float out3[3], int* n_steps) {
-    SG_REQUIRE(d && r && out3, "sg_disc_update_gail_dyn: NULL argument");
+// One epoch of discriminator steps on `rows_local` (device, [TN_loc, F]: this rank's policy rows).
+static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc, int batch_size,
+                            const int64_t* expert_perm, const int64_t* policy_perm, const float* alpha,
+                            uint64_t seed, float out3[3], int* n_steps) {
     sg_ctx* ctx = d->ctx;
     const SgDiscDesc& dd = d->desc;
+    const int rowF = dd.F;
     SG_REQUIRE(d->d_expert, "sg_disc_update_gail_dyn: no expert data (call sg_disc_set_expert first)");
-    SG_REQUIRE(r->F == dd.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, dd.F);
     SG_REQUIRE(batch_size > 0, "sg_disc_update_gail_dyn: batch_size must be positive");
     // Data-parallel modes (world > 1).  "replicated" (default): the discriminator is replicated; once
     // per call the ranks all-gather their next_obs_feat rows, then every rank runs the SAME sequence of
@@ -302,17 +305,16 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     SG_REQUIRE(d->n_expert >= batch_size, "The size of tensor a (%lld) must match the size of tensor b (%d) at "
                "non-singleton dimension 0 (expert rows < gail batch size)", (long long)d->n_expert, batch_size);
     SG_CHECK(hipSetDevice(ctx->device));
-    const int64_t TN_loc = (int64_t)r->T * r->N;
     const int64_t TN = replicated ? TN_loc * world : TN_loc;     // rows the policy permutation ranges over
     const int64_t n_e = d->n_expert / batch_size;   // drop_last (or exactly one full batch)
     const int64_t n_p = TN / B_loc;                 // sharded: local rows contribute batch/world per step
     const int n_d = (int)(n_e < n_p ? n_e : n_p);
     SG_REQUIRE(n_d > 0, "sg_disc_update_gail_dyn: rollout (%lld rows) smaller than one batch (%d)", (long long)TN, B_loc);
     if (n_steps) *n_steps = n_d;
-    const float* next_feat = r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F;
+    const float* next_feat = rows_local;
     if (replicated) {
-        SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * r->F, ctx->stream));
-        SG_TRY(sg_comm_allgather_f32(ctx, next_feat, d->d_feat_all, TN_loc * r->F));
+        SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * rowF, ctx->stream));
+        SG_TRY(sg_comm_allgather_f32(ctx, next_feat, d->d_feat_all, TN_loc * rowF));
         next_feat = d->d_feat_all;
     }
 
@@ -381,7 +383,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
         pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
         wa.next = pg;
         launch_disc_chain(ctx, dd, dim3(2 * G), lds, a);
-        SG_LAUNCH(ctx, SG_PROF_DISC_ADAM, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
+        SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
         if (sharded) {
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
             hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
@@ -394,6 +396,27 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / n_d);
     return 0;
+}
+
+extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm,
+                                       const int64_t* policy_perm, const float* alpha, uint64_t seed,
+                                       float out3[3], int* n_steps) {
+    SG_REQUIRE(d && r && out3, "sg_disc_update_gail_dyn: NULL argument");
+    SG_REQUIRE(r->F == d->desc.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
+    // policy rows = next_obs_feat = obs_feat[1:]   (a2c/storage.py:172, a2c/algo/gail.py:165)
+    return disc_update_core(d, r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F, (int64_t)r->T * r->N, batch_size,
+                            expert_perm, policy_perm, alpha, seed, out3, n_steps);
+}
+
+extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t n_rows, int batch_size,
+                                   const int64_t* expert_perm, const int64_t* policy_perm, const float* alpha,
+                                   uint64_t seed, float out3[3], int* n_steps) {
+    SG_REQUIRE(d && policy_rows && out3 && n_rows > 0, "sg_disc_update_rows: bad argument");
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    SG_TRY(ensure_cap(&d->d_rows, &d->rows_cap, n_rows * d->desc.F, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(d->d_rows, policy_rows, sizeof(float) * (size_t)n_rows * d->desc.F, hipMemcpyHostToDevice, ctx->stream));
+    return disc_update_core(d, d->d_rows, n_rows, batch_size, expert_perm, policy_perm, alpha, seed, out3, n_steps);
 }
 
 static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward) {

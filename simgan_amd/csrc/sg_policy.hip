@@ -5,17 +5,6 @@
 //   Policy.act / get_value / evaluate_actions          a2c/model.py:89-114, a2c/model_split.py:70-95
 //   MLPBase.forward, SplitPolicyBaseNew.forward        a2c/model.py:255-264, a2c/model_split.py:187-198
 //   DiagGaussian / StateDiagGaussianNew / FixedNormal  a2c/distributions.py:51-59,91-118, a2c/model_split.py:201-238
-//   PPO.update                                         a2c/algo/ppo.py:65-157
-//
-// Kernel structure of one PPO optimizer step (E_p * M of them per update, all queued on one
-// stream with no host synchronisation in between):
-//   k_ppo_grad    grid (row groups, 2 parts): part 0 = actor trunk(s), part 1 = critic trunk.
-//                 A workgroup keeps one trunk's parameter block (its exact HBM image) in LDS,
-//                 gathers its minibatch rows by permutation index, runs forward + loss +
-//                 backward entirely on LDS tiles with fp32 MFMA, and writes its partial
-//                 gradient sums to a private slab (deterministic, no atomics).
-//   k_ppo_reduce  sums the slabs per parameter, emits per-block sum-of-squares, bumps Adam's t.
-//   k_ppo_adam    global-norm clip (max_norm/(norm+1e-6), clamped to 1) + Adam.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

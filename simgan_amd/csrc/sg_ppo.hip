@@ -67,23 +67,23 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(256);
 #define SG_CASE(mt, o, h) \
-    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<mt, o, h>), grid, block, lds, pa); return; }
+    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_SHAPES(SG_CASE)
 #undef SG_CASE
-    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<4, 0, 0>), grid, block, lds, pa);
-    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<2, 0, 0>), grid, block, lds, pa);
-    else SG_LAUNCH(ctx, SG_PROF_PPO_GRAD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
+    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<4, 0, 0>), grid, block, lds, pa);
+    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
 }
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(256);
 #define SG_CASE(mt, o, h) \
-    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<mt, o, h>), grid, block, lds, pa); return; }
+    if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_SHAPES(SG_CASE)
 #undef SG_CASE
-    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<4, 0, 0>), grid, block, lds, pa);
-    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<2, 0, 0>), grid, block, lds, pa);
-    else SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, (k_ppo_bwd<1, 0, 0>), grid, block, lds, pa);
+    if (MT == 4) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<4, 0, 0>), grid, block, lds, pa);
+    else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 0, 0>), grid, block, lds, pa);
 }
 
 // ---------------------------------------------------------------------------------- PPO API
@@ -280,15 +280,15 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
             launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
             pa.wbuf_floats = wb_b;
             launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa);
-            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
+            SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
                       d.total, a->d_grad, a->d_part, st);
             if (ctx->use_comm) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
                 hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
             }
-            hipLaunchKernelGGL(k_ppo_adam, dim3(nblk), dim3(256), 0, ctx->stream, a->policy->d_params, a->d_m, a->d_v,
-                               a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
-                               a->d_loss_acc);
+            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
+                      a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
+                      a->d_loss_acc);
         }
     }
     SG_CHECK(hipGetLastError());

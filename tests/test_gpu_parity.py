@@ -194,6 +194,39 @@ def test_disc_update_golden(sg, name):
         assert_close(D.get_flat_params(), g[f"params_after{ep}"], what=f"disc params ep{ep}")
 
 
+class PairDataset:
+    def __init__(self, s, a):
+        self.tensors = (s, a)
+
+
+class PairLoader:
+    """Shape of the reference's DataLoader(TensorDataset(states, actions)) as Discriminator.update reads it."""
+    def __init__(self, s, a, batch_size):
+        self.dataset, self.batch_size = PairDataset(s, a), batch_size
+
+
+@pytest.mark.parametrize("name", ["disc_classic_sa", "disc_classic_dyn"])
+def test_disc_update_classic_golden(sg, name):
+    """Discriminator.update (a2c/algo/gail.py:91-152), both row assemblies, against the reference's output."""
+    g = load(name)
+    m = g["meta"]
+    in_dim = g["e_state"].shape[1] + g["e_action"].shape[1]
+    D = sg.algo.gail.Discriminator(in_dim, m["Hd"], None)
+    D.set_flat_params(g["params0"])
+    ro = sg.RolloutStorage(m["T"], m["N"], (m["O"],), Box((m["A"],)), 1, m["F"])
+    ro.obs.copy_(ro.obs.new_tensor(g["obs"]))
+    ro.actions.copy_(ro.actions.new_tensor(g["actions"]))
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(g["obs_feat"]))
+    filt = None
+    if m["use_filt"]:
+        filt = lambda x, update=False: np.clip((x - g["filt_mean"]) / g["filt_std"], -5.0, 5.0)  # noqa: E731
+    losses = D.update(PairLoader(g["e_state"], g["e_action"], m["B"]), ro, obsfilt=filt, is_gail_dyn=bool(m["dyn"]),
+                      a_dim=m["a_dim"] or None, expert_perm=g["expert_perm"], policy_perm=g["policy_perm"], alpha=g["alpha"])
+    assert D.last_n_steps == int(g["n_steps"])
+    assert_close(losses, g["losses"], what="classic D losses")
+    assert_close(D.get_flat_params(), g["params_after"], what="classic D params")
+
+
 def test_disc_short_expert_is_an_error(sg):
     """Ne < batch: the reference raises on the alpha*expert + (1-alpha)*policy size mismatch."""
     D = sg.algo.gail.Discriminator(7, 16, None)

@@ -108,6 +108,39 @@ def test_disc_update(name):
         assert_close(params, g[f"params_after{ep}"], what=f"disc params ep{ep}")
 
 
+def _classic_rows(g):
+    """Row assembly of Discriminator.update (a2c/algo/gail.py:102-109, 117-122) from a fixture."""
+    m = g["meta"]
+    flat = lambda a: a.reshape(-1, a.shape[-1])  # noqa: E731
+    es = g["e_state"]
+    if m["use_filt"]:
+        es = np.clip((es - g["filt_mean"]) / g["filt_std"], -5.0, 5.0).astype(np.float32)
+    expert = np.concatenate([es, g["e_action"]], axis=1)
+    if m["dyn"]:
+        rows = np.concatenate([flat(g["obs_feat"][:-1]), flat(g["obs"][:-1])[:, -m["a_dim"]:], flat(g["obs_feat"][1:])], axis=1)
+    else:
+        rows = np.concatenate([flat(g["obs"][:-1]), flat(g["actions"])], axis=1)
+    return expert, np.ascontiguousarray(rows, np.float32)
+
+
+@pytest.mark.parametrize("name", ["disc_classic_sa", "disc_classic_dyn"])
+def test_disc_update_classic(name):
+    """Discriminator.update: same step as update_gail_dyn on (state | action) rows; the oracle takes the
+    rows as the [1:] slots of a feature tensor."""
+    g = load(name)
+    m = g["meta"]
+    expert, rows = _classic_rows(g)
+    in_dim = rows.shape[1]
+    feat = np.concatenate([np.zeros((1, m["N"], in_dim), np.float32), rows.reshape(m["T"], m["N"], in_dim)])
+    params = g["params0"].copy()
+    adam = orc.AdamState(params.size)
+    losses, n_d = orc.disc_update(in_dim, m["Hd"], params, adam, expert, feat, m["B"], g["expert_perm"],
+                                  g["policy_perm"], g["alpha"])
+    assert n_d == int(g["n_steps"])
+    assert_close(losses, g["losses"], what="classic D losses")
+    assert_close(params, g["params_after"], what="classic D params")
+
+
 @pytest.mark.parametrize("name", ["relabel_tiny", "relabel_northstar"])
 def test_relabel(name):
     g = load(name)

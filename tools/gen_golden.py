@@ -229,6 +229,38 @@ def gen_disc(name, F, Hd, B, Ne, T, N, epochs, seed):
          expert=expert.numpy(), obs_feat=ro.obs_feat.numpy().copy(), **out)
 
 
+def gen_disc_classic(name, O, A, F, Hd, B, Ne, T, N, dyn, a_dim, use_filt, seed):
+    """Discriminator.update (a2c/algo/gail.py:91-152): the state/action variant and its is_gail_dyn row
+    assembly; the expert loader yields (state, action) pairs, obsfilt normalises the expert states."""
+    from torch.utils.data import DataLoader, TensorDataset
+    torch.manual_seed(seed)
+    in_dim = (F + a_dim + F) if dyn else (O + A)
+    D = ns.Discriminator(in_dim, Hd, "cpu")
+    params0 = flat_params(D.trunk)
+    g = torch.Generator().manual_seed(seed + 1)
+    s_dim = (F + a_dim) if dyn else O
+    e_state = torch.randn(Ne, s_dim, generator=g) * 0.8 + 0.3
+    e_action = torch.randn(Ne, in_dim - s_dim, generator=g) * 0.5
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, F)
+    fill_rollout(ro, T, N, O, A, F, seed + 2)
+    filt_mean = np.linspace(-0.2, 0.3, s_dim).astype(np.float32)
+    filt_std = np.linspace(0.7, 1.4, s_dim).astype(np.float32)
+    obsfilt = (lambda x, update=False: np.clip((x - filt_mean) / filt_std, -5.0, 5.0)) if use_filt else None
+    loader = DataLoader(TensorDataset(e_state, e_action), batch_size=B, shuffle=True, drop_last=Ne > B)
+    _REC.clear()
+    torch.manual_seed(seed + 10)
+    loss = D.update(loader, ro, obsfilt=obsfilt, is_gail_dyn=dyn, a_dim=a_dim if dyn else None)
+    rps = [r for k, r in _REC if k == "randperm"]
+    alphas = [r for k, r in _REC if k == "rand"]
+    assert len(rps[0]) == Ne and len(rps[1]) == T * N
+    save(name, meta=meta(O=O, A=A, F=F, Hd=Hd, B=B, Ne=Ne, T=T, N=N, dyn=int(dyn), a_dim=a_dim, use_filt=int(use_filt)),
+         params0=params0, e_state=e_state.numpy(), e_action=e_action.numpy(), filt_mean=filt_mean, filt_std=filt_std,
+         obs=ro.obs.numpy().copy(), actions=ro.actions.numpy().copy(), obs_feat=ro.obs_feat.numpy().copy(),
+         expert_perm=rps[0].astype(np.int64), policy_perm=rps[1].astype(np.int64),
+         alpha=np.concatenate([a.reshape(-1) for a in alphas]).astype(np.float32),
+         losses=np.array(loss, np.float64), params_after=flat_params(D.trunk), n_steps=np.int64(len(alphas)))
+
+
 # ----------------------------------------------------------------- E. relabel
 def gen_relabel(name, F, Hd, T, N, seed):
     torch.manual_seed(seed)
@@ -376,6 +408,8 @@ if __name__ == "__main__":
     gen_disc("disc_northstar", F=86, Hd=100, B=128, Ne=400, T=8, N=64, epochs=2, seed=310)
     gen_disc("disc_hopper", F=25, Hd=100, B=128, Ne=300, T=16, N=16, epochs=1, seed=320)
     gen_disc("disc_single_batch", F=7, Hd=16, B=8, Ne=8, T=4, N=8, epochs=1, seed=330)  # Ne == B: drop_last False, one batch (Ne < B raises in the reference)
+    gen_disc_classic("disc_classic_sa", O=11, A=3, F=5, Hd=32, B=16, Ne=70, T=6, N=8, dyn=False, a_dim=0, use_filt=True, seed=340)
+    gen_disc_classic("disc_classic_dyn", O=9, A=4, F=6, Hd=32, B=16, Ne=48, T=6, N=8, dyn=True, a_dim=3, use_filt=False, seed=350)
     gen_relabel("relabel_tiny", F=7, Hd=16, T=6, N=5, seed=400)
     gen_relabel("relabel_northstar", F=86, Hd=100, T=8, N=32, seed=410)
     gen_iteration("iter_mlp", "mlp", 47, 12, 64, 1, F=86, Hd=100, T=8, N=16, B=32, Ne=200, E=2, M=2, Ed=2, iters=2, seed=500)
