@@ -170,6 +170,7 @@ struct sg_disc {
     int64_t alpha_cap = 0;
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
+    float* d_wT = nullptr;         // W1^T | W2^T image for k_disc_chain4, maintained by k_disc_wgrad
     float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
     int64_t rows_cap = 0;
     double* d_loss_acc = nullptr;

@@ -27,6 +27,7 @@
 //   dw3 += bd2*s2; sb2 = bd2*w3; z2b = (-2 h2 sb2)*s2; dW2 += z2b h1^T; db2 += z2b
 //   h1b = W2^T z2b - 2 h1 sb1; z1b = h1b*s1; dW1 += z1b x^T; db1 += z1b
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -47,6 +48,25 @@ static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size
     else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<2, 7>), grid, block, lds, a);
     else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<1, 1>), grid, block, lds, a);
     else SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<0, 0>), grid, block, lds, a);
+}
+
+// The 4-row kernel exists for the shipped shapes (everything in it is a compile-time extent);
+// other shapes, or SG_DISC_CHAIN=wide, take the 16-row kernel above.
+static bool disc_chain_thin(const SgDiscDesc& dd) {
+    const char* e = getenv("SG_DISC_CHAIN");
+    if (e && !strcmp(e, "wide")) return false;
+    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
+    return (kf == 6 && kh == 7) || (kf == 2 && kh == 7) || (kf == 1 && kh == 1);
+}
+static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, const DiscArgs& a) {
+    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
+    const dim3 block(512);
+    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<6, 7>), grid, block, 0, a);
+    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<2, 7>), grid, block, 0, a);
+    else SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<1, 1>), grid, block, 0, a);
+}
+static void disc_refresh_transposes(sg_disc* d) {
+    hipLaunchKernelGGL(k_disc_transpose, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
 }
 
 __global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
@@ -183,6 +203,9 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_state, sizeof(SgOptState)));
     SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
+    const size_t wT_f = (size_t)(d->desc.Fp + d->desc.Hp) * d->desc.ldH;
+    SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * wT_f));
+    SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * wT_f, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_v, 0, sizeof(float) * tot, ctx->stream));
@@ -198,7 +221,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
-    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows};
+    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
@@ -234,7 +257,10 @@ static int disc_get(sg_disc* d, const float* dev, float* flat, int64_t n, const 
 
 extern "C" int sg_disc_set_params(sg_disc* d, const float* flat, int64_t n) {
     SG_REQUIRE(d && flat, "sg_disc_set_params: NULL argument");
-    return disc_put(d, d->d_params, flat, n, "sg_disc_set_params");
+    SG_TRY(disc_put(d, d->d_params, flat, n, "sg_disc_set_params"));
+    disc_refresh_transposes(d);
+    SG_CHECK(hipGetLastError());
+    return 0;
 }
 extern "C" int sg_disc_get_params(sg_disc* d, float* flat, int64_t n) {
     SG_REQUIRE(d && flat, "sg_disc_get_params: NULL argument");
@@ -336,7 +362,9 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
 
     const int G = (B_loc + 15) / 16;
     // scratch of one step: operand stacks | per-workgroup vector partials | (data-parallel) flat gradient
-    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)2 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
+    const bool thin = disc_chain_thin(dd);
+    const int n_chain_wg = thin ? 8 * G : 2 * G;
+    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)8 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
@@ -356,11 +384,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     float* stacks[2] = {d->d_slabs, d->d_slabs + ops_f};
     a.part = d->d_slabs + 2 * ops_f; a.st = reinterpret_cast<SgOptState*>(d->d_state);
     a.dbg = d->d_dbg;
+    a.wT = d->d_wT;
     float* grad = d->d_slabs + 2 * ops_f + part_f;
     WgradArgs wa;
     wa.d = dd; wa.part = a.part; wa.G = G; wa.params = d->d_params; wa.m = d->d_m; wa.v = d->d_v;
     wa.grad_out = sharded ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
     wa.loss_acc = d->d_loss_acc;
+    wa.nparts = n_chain_wg; wa.wT = d->d_wT;
     const size_t lds = disc_chain_lds_bytes(dd);
     const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
@@ -382,12 +412,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         pg.eperm = a.eperm + batch_size; pg.alpha = a.alpha + batch_size; pg.pperm = a.pperm + B_loc;
         pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
         wa.next = pg;
-        launch_disc_chain(ctx, dd, dim3(2 * G), lds, a);
+        if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
+        else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
         SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
         if (sharded) {
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
             hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
-                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc);
+                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT);
         }
     }
     SG_CHECK(hipGetLastError());
@@ -534,8 +565,8 @@ extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, 
     SG_REQUIRE(d, "sg_test_disc_phase_times: NULL argument");
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
     if (enable && !d->d_dbg) {
-        SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 64));
-        SG_CHECK(hipMemset(d->d_dbg, 0, sizeof(long long) * 32 * 64));
+        SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 512));
+        SG_CHECK(hipMemset(d->d_dbg, 0, sizeof(long long) * 32 * 512));
     }
     if (out && d->d_dbg) {
         SG_REQUIRE(n_blocks <= 64, "sg_test_disc_phase_times: at most 64 blocks");

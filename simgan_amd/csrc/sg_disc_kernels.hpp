@@ -30,6 +30,7 @@
 //   rows [3nb, 4nb)      mixup workgroup g, second term    L2: z2b   L1: z1b     R2: h1    R1: x~
 #pragma once
 #include "sg_common.h"
+#include "sg_thin.hpp"
 
 struct DiscArgs {
     SgDiscDesc d;
@@ -47,6 +48,7 @@ struct DiscArgs {
     float* part;             // [2G][4*Hp]: db1 | db2 | dw3 | {db3, loss_expert, loss_policy, loss_gp, 0...}
     SgOptState* st;
     long long* dbg;          // optional phase timestamps [block][32] (test hook), NULL in production
+    const float* wT;         // k_disc_chain4: W1^T [Fp][ldH] then W2^T [Hp][ldH], kept in step by k_disc_wgrad
 };
 
 // barrier + (test hook) shader-clock timestamp of the phase that just ended
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
         d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
     }
     const int tid = threadIdx.x;
-    const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp, F = d.F;
+    const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp;
     float* W = smem;
     const float* W1 = W + d.w1;
     const float* b1 = W + d.b1;
@@ -358,6 +360,260 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_disc_chain4<KF,KH>: the same serial part of the step on 4-row blocks (sg_thin.hpp).
+//   grid 8*G workgroups of 512 threads.  Workgroups [0,4G): 4 expert + 4 policy rows (batch rows
+//   4q..4q+3) through forward / BCE / backward-to-activations; workgroups [4G,8G): the 4 matching
+//   mixup rows through the 7 dependent GEMMs of the gradient penalty.  Wave w owns hidden (or
+//   input) columns [16w, 16w+16) in every phase and holds its slice of W1, W2, W1^T and W2^T in
+//   registers (27 x 16 B per lane at F=86, Hd=100), fetched once from L2 while the first phases
+//   already run; LDS carries only the 4-row activations between phases.  Compared with
+//   k_disc_chain the step uses 4x the CUs and a phase costs 28 MFMA issues per wave instead of 56
+//   16x16x4 issues (4x the cycles each).  Operand stacks, partials and math are identical.
+//   Requires compile-time KF, KH <= 8 (one wave per 16 columns, 8 waves).
+template <int KF, int KH>
+__global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
+    constexpr int Fp = 16 * KF, Hp = 16 * KH, ldF = Fp + 4, ldH = Hp + 4;
+    constexpr int ldAF = Fp + 8, ldAH = Hp + 8;   // LDS activation strides: rows 0..3 land in disjoint bank octets
+    constexpr int o_b1 = Hp * ldF, o_w2 = o_b1 + Hp, o_b2 = o_w2 + Hp * ldH, o_w3 = o_b2 + Hp, o_b3 = o_w3 + Hp;
+    __shared__ __attribute__((aligned(16))) float sm[5 * 8 * ldAH + 4 * ldAF + 64];
+    const float* P = a.params;
+    const float* W1T = a.wT;
+    const float* W2T = a.wT + Fp * ldH;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 4, cl = lane & 15;
+    const int col = 16 * wave + cl;
+    const bool actH = wave < KH, actF = wave < KF;
+    const int nb = 16 * a.G, Kt = 4 * nb, G4 = 4 * a.G;
+    float* L2s = a.ops;
+    float* R2s = L2s + (size_t)Kt * ldH;
+    float* L1s = R2s + (size_t)Kt * ldH;
+    float* R1s = L1s + (size_t)Kt * ldH;
+    float* part = a.part + (size_t)blockIdx.x * (4 * Hp);   // db1 | db2 | dw3 | scalars
+    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
+    float4 w1[SG4_NW(Fp)], w2[SG4_NW(Hp)], w2t[SG4_NW(Hp)];
+    float b1c = 0.f, b2c = 0.f, w3c = 0.f;
+
+    if ((int)blockIdx.x < G4) {
+        // ------------------------------------------------ BCE group: row group 0 = 4 expert rows, 1 = 4 policy rows
+        const int bi0 = 4 * blockIdx.x;
+        const int rE0 = 32 * (bi0 >> 4) + (bi0 & 15);            // expert rows rE0+i, policy rows rE0+16+i in the stacks
+        float* H1 = sm;                 // [8][ldAH]
+        float* DZ2 = H1 + 8 * ldAH;     // [8][ldAH]
+        float* LP = DZ2 + 8 * ldAH;     // [8 waves][8 rows] logit partials
+        float4 ax[2][SG4_NCH(Fp)];
+        sg4_load_a<Fp, 2>(ax, R1s + (size_t)rE0 * ldF, ldF, lane, 16);   // pre-gathered by the previous launch
+        if (actH) {
+            sg4_load_w<Fp>(w1, P, ldF, col, lane);
+            b1c = P[o_b1 + col]; b2c = P[o_b2 + col]; w3c = P[o_w3 + col];
+            sg4_load_w<Hp>(w2, P + o_w2, ldH, col, lane);
+            sg4_load_w<Hp>(w2t, W2T, ldH, col, lane);
+        }
+        const float b3 = P[o_b3];
+        float h1[2] = {0.f, 0.f}, h2[2] = {0.f, 0.f};
+        if (actH) {
+            float o[2];
+            sg4_mma<Fp, 2>(ax, w1, lane, o);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                h1[rg] = sg_tanh(o[rg] + b1c);
+                H1[(4 * rg + s) * ldAH + col] = h1[rg];
+                R2s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = h1[rg];
+            }
+        }
+        SG_PHASE_SYNC(1);
+        if (blockIdx.x == 0 && tid == 511) sg_opt_advance(a.st);   // Adam t / bias corrections for the k_disc_wgrad that follows
+        if (actH) {
+            float4 ah[2][SG4_NCH(Hp)];
+            float o[2];
+            sg4_load_a<Hp, 2>(ah, H1, ldAH, lane);
+            sg4_mma<Hp, 2>(ah, w2, lane, o);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                h2[rg] = sg_tanh(o[rg] + b2c);
+                const float pl = sg4_rowsum16(h2[rg] * w3c);
+                if (cl == 0) LP[wave * 8 + 4 * rg + s] = pl;
+            }
+        }
+        SG_PHASE_SYNC(2);
+        {   // logits, BCE losses and dL/dd for this lane's two rows   (a2c/algo/gail.py:168-176)
+            const bool valid = bi0 + s < a.B;
+            float grad[2], loss[2];
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                float dd = b3;
+#pragma unroll
+                for (int w = 0; w < KH; ++w) dd += LP[w * 8 + 4 * rg + s];
+                loss[rg] = 0.f; grad[rg] = 0.f;
+                if (valid) {
+                    if (rg == 0) { loss[rg] = -sg_log_sigmoid(dd); grad[rg] = a.inv_B * (sg_sigmoid(dd) - 1.f); }
+                    else { loss[rg] = dd - sg_log_sigmoid(dd); grad[rg] = a.inv_B * sg_sigmoid(dd); }
+                }
+            }
+            if (actH) {
+                float gw = 0.f, gb = 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const float dz = grad[rg] * w3c * (1.f - h2[rg] * h2[rg]);
+                    gw += grad[rg] * h2[rg];
+                    gb += dz;
+                    DZ2[(4 * rg + s) * ldAH + col] = dz;
+                    L2s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = dz;
+                }
+                gw = sg4_colsum(gw);
+                gb = sg4_colsum(gb);
+                if (s == 0) { part[2 * Hp + col] = gw; part[Hp + col] = gb; }
+            }
+            if (wave == 0) {
+                const float db3 = sg4_colsum(grad[0] + grad[1]), le = sg4_colsum(loss[0]), lp = sg4_colsum(loss[1]);
+                if (lane < 4) part[3 * Hp + lane] = lane == 0 ? db3 : lane == 1 ? le : lane == 2 ? lp : 0.f;
+            }
+        }
+        SG_PHASE_SYNC(3);
+        if (actH) {   // dZ1 = (dZ2 W2) * (1 - h1^2) straight to the left stack; db1 = its column sums
+            float4 ad[2][SG4_NCH(Hp)];
+            float o[2];
+            sg4_load_a<Hp, 2>(ad, DZ2, ldAH, lane);
+            sg4_mma<Hp, 2>(ad, w2t, lane, o);
+            float sb = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                const float dz1 = o[rg] * (1.f - h1[rg] * h1[rg]);
+                L1s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = dz1;
+                sb += dz1;
+            }
+            sb = sg4_colsum(sb);
+            if (s == 0) part[col] = sb;
+        }
+    } else {
+        // ------------------------------------------------ mixup group: gradient penalty on 4 rows
+        const int bi0 = 4 * (blockIdx.x - G4);
+        const int rowA = 2 * nb + bi0, rowB = 3 * nb + bi0;
+        float* H1 = sm;               // [4][ldAH] each
+        float* D2 = H1 + 4 * ldAH;
+        float* D1 = D2 + 4 * ldAH;
+        float* BU1 = D1 + 4 * ldAH;
+        float* Z2B = BU1 + 4 * ldAH;
+        float* GX = sm + 5 * 8 * ldAH;   // [4][ldAF]
+        float4 w1t[SG4_NW(Hp)];
+        float4 ax[1][SG4_NCH(Fp)];
+        sg4_load_a<Fp, 1>(ax, R1s + (size_t)rowB * ldF, ldF, lane);      // pre-gathered mixup rows
+        if (actH) {
+            sg4_load_w<Fp>(w1, P, ldF, col, lane);
+            b1c = P[o_b1 + col]; b2c = P[o_b2 + col]; w3c = P[o_w3 + col];
+            sg4_load_w<Hp>(w2, P + o_w2, ldH, col, lane);
+            sg4_load_w<Hp>(w2t, W2T, ldH, col, lane);
+        }
+        if (actF) sg4_load_w<Hp>(w1t, W1T, ldH, col, lane);
+        float h1 = 0.f, h2 = 0.f, u1 = 0.f, sb1 = 0.f, gown = 0.f;
+        if (actH) {
+            float o[1];
+            sg4_mma<Fp, 1>(ax, w1, lane, o);
+            h1 = sg_tanh(o[0] + b1c);
+            H1[s * ldAH + col] = h1;
+            R2s[(size_t)(rowB + s) * ldH + col] = h1;
+        }
+        SG_PHASE_SYNC(8);
+        if (actH) {
+            float4 av[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(av, H1, ldAH, lane);
+            sg4_mma<Hp, 1>(av, w2, lane, o);
+            h2 = sg_tanh(o[0] + b2c);
+            const float d2 = w3c * (1.f - h2 * h2);
+            D2[s * ldAH + col] = d2;
+            L2s[(size_t)(rowA + s) * ldH + col] = d2;
+        }
+        SG_PHASE_SYNC(9);
+        if (actH) {   // u1 = d2 W2
+            float4 av[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(av, D2, ldAH, lane);
+            sg4_mma<Hp, 1>(av, w2t, lane, o);
+            u1 = o[0];
+            const float d1 = u1 * (1.f - h1 * h1);
+            D1[s * ldAH + col] = d1;
+            L1s[(size_t)(rowA + s) * ldH + col] = d1;
+        }
+        SG_PHASE_SYNC(10);
+        if (actF) {   // g = d1 W1
+            float4 av[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(av, D1, ldAH, lane);
+            sg4_mma<Hp, 1>(av, w1t, lane, o);
+            gown = o[0];
+            GX[s * ldAF + col] = gown;
+        }
+        SG_PHASE_SYNC(11);
+        {   // per-row |g|, penalty coefficient (a2c/algo/gail.py:88), then bd1 = (c_r g) W1^T; every wave
+            // recomputes the four norms from LDS instead of spending a barrier on them
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < KF; ++q) { const float v = GX[s * ldAF + 16 * q + cl]; ss += v * v; }
+            ss = sg4_rowsum16(ss);
+            const float nn = sqrtf(ss);
+            const bool valid = bi0 + s < a.B;
+            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
+            if (actF) R1s[(size_t)(rowA + s) * ldF + col] = gown * cr;           // gb
+            if (wave == 0) {
+                const float rl = sg4_colsum(valid ? (nn - 1.f) * (nn - 1.f) : 0.f);
+                if (lane < 4) part[3 * Hp + lane] = lane == 3 ? rl : 0.f;         // sum (|g|-1)^2
+            }
+            const float cri = __shfl(cr, 16 * (lane & 3));                         // coefficient of this lane's A row
+            if (actH) {
+                float4 av[1][SG4_NCH(Fp)];
+                float o[1];
+                sg4_load_a<Fp, 1>(av, GX, ldAF, lane);
+#pragma unroll
+                for (int tc = 0; tc < SG4_NCH(Fp); ++tc) { av[0][tc].x *= cri; av[0][tc].y *= cri; av[0][tc].z *= cri; av[0][tc].w *= cri; }
+                sg4_mma<Fp, 1>(av, w1, lane, o);
+                const float bd1 = o[0];
+                const float bu1 = bd1 * (1.f - h1 * h1);
+                BU1[s * ldAH + col] = bu1;
+                R2s[(size_t)(rowA + s) * ldH + col] = bu1;
+                sb1 = bd1 * u1;
+            }
+        }
+        SG_PHASE_SYNC(13);
+        if (actH) {   // bd2 = bu1 W2^T
+            float4 av[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(av, BU1, ldAH, lane);
+            sg4_mma<Hp, 1>(av, w2, lane, o);
+            const float s2 = 1.f - h2 * h2, bd2 = o[0];
+            const float t3 = bd2 * s2;                                   // -> dw3
+            const float z2b = (-2.f * h2 * (bd2 * w3c)) * s2;
+            Z2B[s * ldAH + col] = z2b;
+            L2s[(size_t)(rowB + s) * ldH + col] = z2b;
+            const float sw = sg4_colsum(t3), sb = sg4_colsum(z2b);
+            if (s == 0) { part[2 * Hp + col] = sw; part[Hp + col] = sb; }
+        }
+        SG_PHASE_SYNC(14);
+        if (actH) {   // h1b = z2b W2
+            float4 av[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(av, Z2B, ldAH, lane);
+            sg4_mma<Hp, 1>(av, w2t, lane, o);
+            const float z1b = (o[0] - 2.f * h1 * sb1) * (1.f - h1 * h1);
+            L1s[(size_t)(rowB + s) * ldH + col] = z1b;
+            const float sb = sg4_colsum(z1b);
+            if (s == 0) part[col] = sb;
+        }
+    }
+    SG_PHASE_SYNC(31);
+}
+
+// W1^T / W2^T image for k_disc_chain4 from the padded parameter vector (after sg_disc_set_params).
+__global__ __launch_bounds__(256) void k_disc_transpose(SgDiscDesc d, const float* params, float* wT) {
+    const int n1 = d.Fp * d.ldH, n2 = d.Hp * d.ldH;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
+        const bool one = i < n1;
+        const int j = one ? i : i - n1, r = j / d.ldH, c = j % d.ldH;
+        float v = 0.f;
+        if (c < d.Hp) v = one ? params[d.w1 + c * d.ldF + r] : params[d.w2 + c * d.ldH + r];
+        wT[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct WgradArgs {
     SgDiscDesc d;
     const float* ops;
@@ -369,6 +625,8 @@ struct WgradArgs {
     float eps, inv_B, lambda_;
     double* loss_acc;
     PregatherArgs next;       // next step's inputs (next.ops == NULL on the last step)
+    int nparts;               // workgroups of the chain kernel (rows of `part`)
+    float* wT;                // transposed weight image to keep in step (NULL: not maintained)
 };
 
 // torch.optim.Adam single-tensor math (a2c/algo/gail.py:48,186-188: lr 1e-3, eps 1e-8)
@@ -447,15 +705,25 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
                 m0 = m0 + (g - m0) * (float)(1.0 - 0.9);
                 v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
                 const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
-                a.params[idx] = p0 - step_size * (m0 / denom);
+                p0 = p0 - step_size * (m0 / denom);
+                a.params[idx] = p0;
                 a.m[idx] = m0;
                 a.v[idx] = v0;
+            }
+        }
+        if (a.wT && !a.grad_out) {   // the tile's transpose, through LDS so both images are written in 64-byte runs
+            __syncthreads();
+            if (tid < 256) red[0][tid] = p0;
+            __syncthreads();
+            if (tid < 256) {
+                float* T = a.wT + (w2 ? (size_t)d.Fp * d.ldH : (size_t)0);
+                T[(size_t)(tn * 16 + (tid >> 4)) * d.ldH + tm * 16 + (tid & 15)] = red[0][(tid & 15) * 16 + (tid >> 4)];
             }
         }
     } else {
         // vectors: db1 | db2 | dw3 | db3 from the per-workgroup partials, and the loss sums
         const float step_size = a.st->step_size, bc2_sqrt = a.st->bc2_sqrt;
-        const int Hp = d.Hp, nparts = 2 * a.G, stride = 4 * Hp;
+        const int Hp = d.Hp, nparts = a.nparts, stride = 4 * Hp;
         for (int i = tid; i < 3 * Hp + 4; i += blockDim.x) {
             float g = 0.f;
             for (int s = 0; s < nparts; ++s) g += a.part[(size_t)s * stride + i];
@@ -485,9 +753,15 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
 // Data-parallel mode only: Adam from the all-reduced flat gradient (+ loss sums in its tail).
 __global__ __launch_bounds__(256) void k_disc_adam_flat(float* params, float* m, float* v, const float* grad, int total,
                                                         const SgOptState* st, float eps, float inv_B, float lambda_,
-                                                        double* loss_acc) {
+                                                        double* loss_acc, SgDiscDesc d, float* wT) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size, st->bc2_sqrt, eps);
+    if (i < total) {
+        sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size, st->bc2_sqrt, eps);
+        if (wT) {
+            if (i < d.b1) { const int r = i / d.ldF, c = i % d.ldF; if (c < d.Fp) wT[c * d.ldH + r] = params[i]; }
+            else if (i >= d.w2 && i < d.b2) { const int j = i - d.w2, r = j / d.ldH, c = j % d.ldH; if (c < d.Hp) wT[(d.Fp + c) * d.ldH + r] = params[i]; }
+        }
+    }
     if (i == 0) {
         const float el = grad[total] * inv_B, pl = grad[total + 1] * inv_B, gp = lambda_ * (grad[total + 2] * inv_B);
         loss_acc[0] += (double)(el + pl + gp);

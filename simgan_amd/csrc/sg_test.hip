@@ -2,6 +2,7 @@
 #include <vector>
 
 #include "sg_common.h"
+#include "sg_thin.hpp"
 
 struct GemmTestArgs {
     int mode, M, N, K;
@@ -37,9 +38,77 @@ __global__ __launch_bounds__(256) void k_gemm_test(GemmTestArgs a) {
     for (int i = threadIdx.x; i < a.M * a.N; i += blockDim.x) a.C[i] = Cs[(i / a.N) * ldc + i % a.N];
 }
 
+// mode 3: thin-row engine (sg_thin.hpp).  A[M,K] with M = 4 or 8, B[N,K] with N <= 128; one wave per 16 columns.
+template <int K, int RG>
+__global__ __launch_bounds__(512) void k_thin_test(GemmTestArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (16 * wave >= a.N) return;
+    float4 w[SG4_NW(K)];
+    float4 x[RG][SG4_NCH(K)];
+    float out[RG];
+    sg4_load_w<K>(w, a.B, K, 16 * wave + (lane & 15), lane);
+    sg4_load_a<K, RG>(x, a.A, K, lane);
+    sg4_mma<K, RG>(x, w, lane, out);
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) a.C[(size_t)(4 * rg + (lane >> 4)) * a.N + 16 * wave + (lane & 15)] = out[rg];
+}
+
+template <int K>
+static void launch_thin_test(sg_ctx* ctx, const GemmTestArgs& a) {
+    if (a.M == 8) hipLaunchKernelGGL((k_thin_test<K, 2>), dim3(1), dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thin_test<K, 1>), dim3(1), dim3(512), 0, ctx->stream, a);
+}
+
+// raw v_mfma_f32_4x4x1 with CBSZ=2: d[lane][0..3] for given per-lane a, b and ABID (documents the operand layout)
+__global__ void k_mfma_probe(const float* av, const float* bv, int abid, float* d) {
+    const int l = threadIdx.x;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (abid == 0) acc = sg4_mfma<0>(av[l], bv[l], acc);
+    else if (abid == 1) acc = sg4_mfma<1>(av[l], bv[l], acc);
+    else if (abid == 2) acc = sg4_mfma<2>(av[l], bv[l], acc);
+    else acc = sg4_mfma<3>(av[l], bv[l], acc);
+    for (int r = 0; r < 4; ++r) d[4 * l + r] = acc[r];
+}
+
+extern "C" int sg_test_mfma_probe(sg_ctx* ctx, int abid, const float* a, const float* b, float* d) {
+    SG_REQUIRE(ctx && a && b && d && abid >= 0 && abid < 4, "sg_test_mfma_probe: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    float *da, *db, *dd;
+    SG_CHECK(hipMalloc((void**)&da, 256)); SG_CHECK(hipMalloc((void**)&db, 256)); SG_CHECK(hipMalloc((void**)&dd, 1024));
+    SG_CHECK(hipMemcpy(da, a, 256, hipMemcpyHostToDevice));
+    SG_CHECK(hipMemcpy(db, b, 256, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, ctx->stream, da, db, abid, dd);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_CHECK(hipMemcpy(d, dd, 1024, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+    return 0;
+}
+
 extern "C" int sg_test_gemm(sg_ctx* ctx, int mode, int M, int N, int K, const float* A, const float* B, float* C) {
     SG_REQUIRE(ctx && A && B && C, "sg_test_gemm: NULL argument");
-    SG_REQUIRE(mode >= 0 && mode <= 2, "sg_test_gemm: mode must be 0 (NT), 1 (NN) or 2 (TN)");
+    if (mode == 3) {
+        SG_REQUIRE((M == 4 || M == 8) && N % 16 == 0 && N > 0 && N <= 128 && (K == 16 || K == 32 || K == 96 || K == 112),
+                   "sg_test_gemm: thin mode needs M in {4,8}, N a multiple of 16 <= 128, K in {16,32,96,112}");
+        SG_CHECK(hipSetDevice(ctx->device));
+        float *dA, *dB, *dC;
+        SG_CHECK(hipMalloc((void**)&dA, sizeof(float) * M * K));
+        SG_CHECK(hipMalloc((void**)&dB, sizeof(float) * N * K));
+        SG_CHECK(hipMalloc((void**)&dC, sizeof(float) * M * N));
+        SG_CHECK(hipMemcpy(dA, A, sizeof(float) * M * K, hipMemcpyHostToDevice));
+        SG_CHECK(hipMemcpy(dB, B, sizeof(float) * N * K, hipMemcpyHostToDevice));
+        GemmTestArgs a{mode, M, N, K, dA, dB, dC};
+        if (K == 16) launch_thin_test<16>(ctx, a);
+        else if (K == 32) launch_thin_test<32>(ctx, a);
+        else if (K == 96) launch_thin_test<96>(ctx, a);
+        else launch_thin_test<112>(ctx, a);
+        SG_CHECK(hipGetLastError());
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        SG_CHECK(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
+        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+        return 0;
+    }
+    SG_REQUIRE(mode >= 0 && mode <= 2, "sg_test_gemm: mode must be 0 (NT), 1 (NN), 2 (TN) or 3 (thin NT)");
     SG_REQUIRE(M % 16 == 0 && N % 16 == 0 && K % 16 == 0 && M > 0 && N > 0 && K > 0, "sg_test_gemm: dims must be positive multiples of 16");
     SG_REQUIRE(mode == 2 || M == 16 || M == 32 || M == 64, "sg_test_gemm: M must be 16, 32 or 64 for NT/NN");
     SG_CHECK(hipSetDevice(ctx->device));

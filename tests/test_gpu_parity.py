@@ -177,8 +177,10 @@ class Loader:  # stands in for torch DataLoader(TensorDataset(expert), batch_siz
 DISC_CASES = ["disc_tiny", "disc_northstar", "disc_hopper", "disc_single_batch"]
 
 
+@pytest.mark.parametrize("chain", ["thin", "wide"])   # 4-row (v_mfma 4x4x1) and 16-row (16x16x4) chain kernels
 @pytest.mark.parametrize("name", DISC_CASES)
-def test_disc_update_golden(sg, name):
+def test_disc_update_golden(sg, name, chain, monkeypatch):
+    monkeypatch.setenv("SG_DISC_CHAIN", chain)
     g = load(name)
     m = g["meta"]
     D = sg.algo.gail.Discriminator(m["F"], m["Hd"], None)
