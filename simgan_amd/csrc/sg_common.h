@@ -170,7 +170,8 @@ struct sg_disc {
     int64_t alpha_cap = 0;
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
-    float* d_wT = nullptr;         // W1^T | W2^T image for k_disc_chain4, maintained by k_disc_wgrad
+    int64_t opt_t = 0;             // completed Adam steps (the device only sees per-step scalars)
+    float* d_wT = nullptr;         // weight images W1 | W2 | W2^T | W1^T of k_disc_chain4, maintained by k_disc_wgrad
     float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
     int64_t rows_cap = 0;
     double* d_loss_acc = nullptr;
@@ -188,7 +189,10 @@ struct SgOptState {
     float step;       // Adam t (exact in fp32 up to 2^24 steps)
     float step_size;  // lr / (1 - beta1^t), refreshed by sg_opt_advance()
     float bc2_sqrt;   // sqrt(1 - beta2^t)
-    float pad[4];
+    // discriminator: the same two scalars for step t in slot t & 1, written one step ahead by a spare lane of
+    // the previous optimizer kernel (sg_opt_prepare) so nothing on the step's critical path evaluates pow()
+    float step_size2[2];
+    float bc2_sqrt2[2];
 };
 
 #ifdef __HIPCC__
@@ -200,6 +204,12 @@ __device__ __forceinline__ void sg_opt_advance(SgOptState* st) {
     const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
     st->step_size = (float)((double)st->lr / bc1);
     st->bc2_sqrt = (float)sqrt(bc2);
+}
+// bias-correction scalars of Adam step t (1-based) into slot t & 1
+__device__ __forceinline__ void sg_opt_prepare(SgOptState* st, int t) {
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    st->step_size2[t & 1] = (float)((double)st->lr / bc1);
+    st->bc2_sqrt2[t & 1] = (float)sqrt(bc2);
 }
 #endif
 

@@ -27,9 +27,11 @@
 //   dw3 += bd2*s2; sb2 = bd2*w3; z2b = (-2 h2 sb2)*s2; dW2 += z2b h1^T; db2 += z2b
 //   h1b = W2^T z2b - 2 h1 sb1; z1b = h1b*s1; dW1 += z1b x^T; db1 += z1b
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "sg_common.h"
@@ -65,8 +67,8 @@ static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, con
     else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<2, 7>), grid, block, 0, a);
     else SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<1, 1>), grid, block, 0, a);
 }
-static void disc_refresh_transposes(sg_disc* d) {
-    hipLaunchKernelGGL(k_disc_transpose, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
+static void disc_refresh_images(sg_disc* d) {
+    hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
 }
 
 __global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
@@ -203,7 +205,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_state, sizeof(SgOptState)));
     SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
-    const size_t wT_f = (size_t)(d->desc.Fp + d->desc.Hp) * d->desc.ldH;
+    const size_t wT_f = (size_t)2 * d->desc.Hp * (d->desc.Fp + d->desc.Hp);   // images of W1, W2, W2^T, W1^T
     SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * wT_f));
     SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * wT_f, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
@@ -258,7 +260,7 @@ static int disc_get(sg_disc* d, const float* dev, float* flat, int64_t n, const 
 extern "C" int sg_disc_set_params(sg_disc* d, const float* flat, int64_t n) {
     SG_REQUIRE(d && flat, "sg_disc_set_params: NULL argument");
     SG_TRY(disc_put(d, d->d_params, flat, n, "sg_disc_set_params"));
-    disc_refresh_transposes(d);
+    disc_refresh_images(d);
     SG_CHECK(hipGetLastError());
     return 0;
 }
@@ -270,17 +272,15 @@ extern "C" int sg_disc_get_adam(sg_disc* d, float* m, float* v, int64_t n, int64
     SG_REQUIRE(d && m && v && step, "sg_disc_get_adam: NULL argument");
     SG_TRY(disc_get(d, d->d_m, m, n, "sg_disc_get_adam"));
     SG_TRY(disc_get(d, d->d_v, v, n, "sg_disc_get_adam"));
-    SgOptState st;
-    SG_CHECK(hipMemcpy(&st, d->d_state, sizeof st, hipMemcpyDeviceToHost));
-    *step = (int64_t)st.step;
+    *step = d->opt_t;
     return 0;
 }
 extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int64_t n, int64_t step) {
     SG_REQUIRE(d && m && v, "sg_disc_set_adam: NULL argument");
     SG_TRY(disc_put(d, d->d_m, m, n, "sg_disc_set_adam"));
     SG_TRY(disc_put(d, d->d_v, v, n, "sg_disc_set_adam"));
-    const float fs = (float)step;
-    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(d->d_state)->step, &fs, sizeof(float), hipMemcpyHostToDevice));
+    SG_REQUIRE(step >= 0, "sg_disc_set_adam: negative step");
+    d->opt_t = step;
     return 0;
 }
 
@@ -363,8 +363,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int G = (B_loc + 15) / 16;
     // scratch of one step: operand stacks | per-workgroup vector partials | (data-parallel) flat gradient
     const bool thin = disc_chain_thin(dd);
-    const int n_chain_wg = thin ? 8 * G : 2 * G;
-    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)8 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
+    const int n_chain_wg = thin ? 12 * G : 2 * G;
+    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
@@ -390,10 +390,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     wa.d = dd; wa.part = a.part; wa.G = G; wa.params = d->d_params; wa.m = d->d_m; wa.v = d->d_v;
     wa.grad_out = sharded ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
     wa.loss_acc = d->d_loss_acc;
-    wa.nparts = n_chain_wg; wa.wT = d->d_wT;
+    wa.nparts = n_chain_wg; wa.wT = d->d_wT; wa.dbg = d->d_dbg;
     const size_t lds = disc_chain_lds_bytes(dd);
     const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
+    const int n_vec = (3 * dd.Hp + 4 + 63) / 64;
+    const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
+    const auto t_enq0 = std::chrono::steady_clock::now();
     for (int k = 0; k < n_d; ++k) {
         // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
         const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
@@ -404,7 +407,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         wa.ops = a.ops;
         PregatherArgs pg;
         pg.expert = d->d_expert; pg.next_feat = a.next_feat; pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp;
-        pg.ldF = dd.ldF; pg.ldH = dd.ldH;
+        pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st; pg.t = (int)(d->opt_t + k + 1);
+        wa.t = pg.t;
         if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
             pg.eperm = a.eperm; pg.pperm = a.pperm; pg.alpha = a.alpha; pg.ops = a.ops;
             hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
@@ -414,18 +418,26 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         wa.next = pg;
         if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
         else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
-        SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + 1 + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
+        SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + n_vec + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
         if (sharded) {
             SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
             hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
-                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT);
+                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT, wa.t);
         }
     }
     SG_CHECK(hipGetLastError());
+    const auto t_enq1 = std::chrono::steady_clock::now();
     double acc[3];
     SG_CHECK(hipMemcpyAsync(acc, d->d_loss_acc, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
+    if (dbg_timing) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sg] disc epoch: %d steps, enqueue %.3f ms, enqueue->done %.3f ms\n", n_d,
+                std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(),
+                std::chrono::duration<double, std::milli>(t_done - t_enq1).count());
+    }
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / n_d);
+    d->opt_t += n_d;
     return 0;
 }
 
@@ -569,8 +581,8 @@ extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, 
         SG_CHECK(hipMemset(d->d_dbg, 0, sizeof(long long) * 32 * 512));
     }
     if (out && d->d_dbg) {
-        SG_REQUIRE(n_blocks <= 64, "sg_test_disc_phase_times: at most 64 blocks");
-        SG_CHECK(hipMemcpy(out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));
+        SG_REQUIRE(n_blocks <= 512, "sg_test_disc_phase_times: at most 512 blocks");
+        SG_CHECK(hipMemcpy(out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));   // n_blocks = 512: + k_disc_wgrad stamps
     }
     if (!enable && d->d_dbg) { SG_CHECK(hipFree(d->d_dbg)); d->d_dbg = nullptr; }
     return 0;

@@ -48,7 +48,7 @@ struct DiscArgs {
     float* part;             // [2G][4*Hp]: db1 | db2 | dw3 | {db3, loss_expert, loss_policy, loss_gp, 0...}
     SgOptState* st;
     long long* dbg;          // optional phase timestamps [block][32] (test hook), NULL in production
-    const float* wT;         // k_disc_chain4: W1^T [Fp][ldH] then W2^T [Hp][ldH], kept in step by k_disc_wgrad
+    const float* wT;         // k_disc_chain4: weight images W1 | W2 | W2^T | W1^T (sg4_img_index), kept in step by k_disc_wgrad
 };
 
 // barrier + (test hook) shader-clock timestamp of the phase that just ended
@@ -69,6 +69,19 @@ __device__ __forceinline__ float sg_rowlane_sum(float s, int L) {
 
 #define SG_DISC_THREADS 512
 
+// Operand stacks of one step.  L2, R2, L1 (Hp columns) and R1t (Fp columns) are stored one 16-column tile
+// after another, each tile as [Kt rows][16] (SG_STK): the [K x 16] slab a weight-gradient workgroup
+// contracts over is then one contiguous run of whole cache lines.  R1 is ALSO kept row-major
+// ([Kt][ldF]) for rows the chain kernels read back as GEMM input (the pre-gathered batch rows).
+#define SG_STK(Kt, row, c) ((((size_t)((c) >> 4)) * (size_t)(Kt) + (size_t)(row)) * 16 + ((c) & 15))
+struct SgStacks { float *L2, *R2, *L1, *R1, *R1t; };
+__host__ __device__ __forceinline__ SgStacks sg_disc_stacks(float* ops, int Kt, int Hp, int Fp, int ldF) {
+    SgStacks k;
+    k.L2 = ops; k.R2 = k.L2 + (size_t)Kt * Hp; k.L1 = k.R2 + (size_t)Kt * Hp; k.R1 = k.L1 + (size_t)Kt * Hp;
+    k.R1t = k.R1 + (size_t)Kt * ldF;
+    return k;
+}
+
 static size_t disc_chain_lds_bytes(const SgDiscDesc& d) {
     const size_t bce = (size_t)32 * d.ldF + 2 * 32 * d.ldH + 64;
     const size_t mix = (size_t)2 * 16 * d.ldF + 7 * 16 * d.ldH + 64;
@@ -76,7 +89,7 @@ static size_t disc_chain_lds_bytes(const SgDiscDesc& d) {
 }
 static size_t disc_ops_floats(const SgDiscDesc& d, int G) {
     const size_t Kt = (size_t)64 * G;
-    return Kt * (3 * (size_t)d.ldH + d.ldF);
+    return Kt * (3 * (size_t)d.Hp + d.ldF + d.Fp);
 }
 
 // Input rows of ONE chain workgroup of the NEXT step, gathered by permutation index into the right
@@ -92,12 +105,16 @@ struct PregatherArgs {
     const int64_t* pperm;
     const float* alpha;
     float* ops;     // operand stacks of the step being prepared
-    int B, G, F, Fp, ldF, ldH;
+    int B, G, F, Fp, ldF, Hp;
+    SgOptState* st; // Adam scalars of step t are prepared alongside (one lane)
+    int t;
 };
 
 __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j) {
     const int nb = 16 * p.G, Kt = 4 * nb;
-    float* R1s = p.ops + (size_t)3 * Kt * p.ldH;
+    const SgStacks stk = sg_disc_stacks(p.ops, Kt, p.Hp, p.Fp, p.ldF);
+    float* R1s = stk.R1;
+    float* R1t = stk.R1t;
     const int Fp = p.Fp, F = p.F;
     const bool bce = j < p.G;
     const int g = bce ? j : j - p.G;
@@ -122,12 +139,18 @@ __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + u * blockDim.x;
-            if (i < rows * Fp) R1s[(size_t)(row0 + i / Fp) * p.ldF + (i % Fp)] = v[u];
+            if (i < rows * Fp) {
+                R1s[(size_t)(row0 + i / Fp) * p.ldF + (i % Fp)] = v[u];
+                R1t[SG_STK(Kt, row0 + i / Fp, i % Fp)] = v[u];
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(512) void k_disc_pregather(PregatherArgs p) { sg_disc_pregather(p, blockIdx.x); }
+__global__ __launch_bounds__(512) void k_disc_pregather(PregatherArgs p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sg_opt_prepare(p.st, p.t);
+    sg_disc_pregather(p, blockIdx.x);
+}
 
 // KF = pad16(F)/16 and KH = pad16(Hd)/16 as compile-time constants (0 = take them from the
 // descriptor at run time): with the shape fixed, every GEMM extent, LDS offset and staging trip
@@ -152,10 +175,12 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
     const float* w3 = W + d.w3;
     float* buf = W + d.total;
     const int nb = 16 * a.G, Kt = 4 * nb;
-    float* L2s = a.ops;
-    float* R2s = L2s + (size_t)Kt * ldH;
-    float* L1s = R2s + (size_t)Kt * ldH;
-    float* R1s = L1s + (size_t)Kt * ldH;
+    const SgStacks stk = sg_disc_stacks(a.ops, Kt, Hp, Fp, ldF);
+    float* L2s = stk.L2;
+    float* R2s = stk.R2;
+    float* L1s = stk.L1;
+    float* R1s = stk.R1;     // row-major: pre-gathered input rows
+    float* R1t = stk.R1t;    // tiled: gb rows for the weight gradient
     float* part = a.part + (size_t)blockIdx.x * (4 * Hp);   // db1 | db2 | dw3 | scalars
     if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
 
@@ -181,13 +206,10 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
         }
         sg_stage_commit<12>(W, wv, a.params, d.total / 4);
         SG_PHASE_SYNC(1);
-        // Adam t / bias corrections for the k_disc_wgrad that follows: one lane of the last wave, which
-        // has no tile in the 7-tile GEMM phases, so the double-precision pow() hides behind them
-        if (blockIdx.x == 0 && tid == (int)blockDim.x - 64) sg_opt_advance(a.st);
         sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
             const float h = sg_tanh(v + b1[c]);
             H1[r * ldH + c] = h;
-            R2s[(size_t)(row0 + r) * ldH + c] = h;
+            R2s[SG_STK(Kt, row0 + r, c)] = h;
         });
         SG_PHASE_SYNC(2);
         sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
                 const float dz = dd * w * (1.f - h * h);
                 gb += dz;
                 H2[r * ldH + c] = dz;
-                L2s[(size_t)(row0 + r) * ldH + c] = dz;
+                L2s[SG_STK(Kt, row0 + r, c)] = dz;
             }
             part[2 * Hp + c] = gw;
             part[Hp + c] = gb;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
                     const int row = i * 16 + 4 * lq + r;
                     const float h = H1[row * ldH + c];
                     z[i][r] = acc[i][0][r] * (1.f - h * h);
-                    L1s[(size_t)(row0 + row) * ldH + c] = z[i][r];
+                    L1s[SG_STK(Kt, row0 + row, c)] = z[i][r];
                 }
             const float sb = sg_tile_colsum<2>(z);
             if (lq == 0) part[c] = sb;
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
         sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
             const float h = sg_tanh(v + b1[c]);
             H1[r * ldH + c] = h;
-            R2s[(size_t)(rowB + r) * ldH + c] = h;
+            R2s[SG_STK(Kt, rowB + r, c)] = h;
         });
         SG_PHASE_SYNC(9);
         sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             const float d2 = w3[c] * (1.f - h * h);
             H2[r * ldH + c] = h;
             D2[r * ldH + c] = d2;
-            L2s[(size_t)(rowA + r) * ldH + c] = d2;
+            L2s[SG_STK(Kt, rowA + r, c)] = d2;
         });
         SG_PHASE_SYNC(10);
         sg_layer_nn<1>(D2, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {      // u1 = d2 W2
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             const float d1 = v * (1.f - h * h);
             U1[r * ldH + c] = v;
             D1[r * ldH + c] = d1;
-            L1s[(size_t)(rowA + r) * ldH + c] = d1;
+            L1s[SG_STK(Kt, rowA + r, c)] = d1;
         });
         SG_PHASE_SYNC(11);
         sg_layer_nn<1>(D1, ldH, W1, ldF, Hp, Fp, [&](int r, int c, float v) { GX[r * ldF + c] = v; });  // g = d1 W1
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             for (int c = sub; c < Fp; c += L) {
                 const float gb = GX[r * ldF + c] * cr;
                 GX[r * ldF + c] = gb;
-                R1s[(size_t)(rowA + r) * ldF + c] = gb;
+                R1t[SG_STK(Kt, rowA + r, c)] = gb;
             }
             if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
         }
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             const float h = H1[r * ldH + c];
             const float bu1 = v * (1.f - h * h);
             BU1[r * ldH + c] = bu1;
-            R2s[(size_t)(rowA + r) * ldH + c] = bu1;
+            R2s[SG_STK(Kt, rowA + r, c)] = bu1;
             U1[r * ldH + c] = v * U1[r * ldH + c];                                  // sb1 = bd1*u1
         });
         SG_PHASE_SYNC(14);
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
                 t3[0][r] = v * s2;                                                  // -> dw3
                 z[0][r] = (-2.f * h * (v * w)) * s2;                                // z2b
                 Z2B[row * ldH + c] = z[0][r];
-                L2s[(size_t)(rowB + row) * ldH + c] = z[0][r];
+                L2s[SG_STK(Kt, rowB + row, c)] = z[0][r];
             }
             const float sw = sg_tile_colsum<1>(t3), sb = sg_tile_colsum<1>(z);
             if (lq == 0) { part[2 * Hp + c] = sw; part[Hp + c] = sb; }
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
                 const int row = 4 * lq + r;
                 const float h = H1[row * ldH + c];
                 z[0][r] = (acc[0][0][r] - 2.f * h * U1[row * ldH + c]) * (1.f - h * h);  // z1b
-                L1s[(size_t)(rowB + row) * ldH + c] = z[0][r];
+                L1s[SG_STK(Kt, rowB + row, c)] = z[0][r];
             }
             const float sb = sg_tile_colsum<1>(z);
             if (lq == 0) part[c] = sb;
@@ -361,9 +383,9 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // k_disc_chain4<KF,KH>: the same serial part of the step on 4-row blocks (sg_thin.hpp).
-//   grid 8*G workgroups of 512 threads.  Workgroups [0,4G): 4 expert + 4 policy rows (batch rows
-//   4q..4q+3) through forward / BCE / backward-to-activations; workgroups [4G,8G): the 4 matching
-//   mixup rows through the 7 dependent GEMMs of the gradient penalty.  Wave w owns hidden (or
+//   grid 12*G workgroups of 512 threads.  Workgroups [0,4G): 4 mixup rows (batch rows 4q..4q+3) through
+//   the 7 dependent GEMMs of the gradient penalty; workgroups [4G,12G): the matching 4 expert rows (even)
+//   or 4 policy rows (odd) through forward / BCE / backward-to-activations.  Wave w owns hidden (or
 //   input) columns [16w, 16w+16) in every phase and holds its slice of W1, W2, W1^T and W2^T in
 //   registers (27 x 16 B per lane at F=86, Hd=100), fetched once from L2 while the first phases
 //   already run; LDS carries only the 4-row activations between phases.  Compared with
@@ -374,142 +396,141 @@ template <int KF, int KH>
 __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
     constexpr int Fp = 16 * KF, Hp = 16 * KH, ldF = Fp + 4, ldH = Hp + 4;
     constexpr int ldAF = Fp + 8, ldAH = Hp + 8;   // LDS activation strides: rows 0..3 land in disjoint bank octets
-    constexpr int o_b1 = Hp * ldF, o_w2 = o_b1 + Hp, o_b2 = o_w2 + Hp * ldH, o_w3 = o_b2 + Hp, o_b3 = o_w3 + Hp;
-    __shared__ __attribute__((aligned(16))) float sm[5 * 8 * ldAH + 4 * ldAF + 64];
+    constexpr int o_b1 = Hp * ldF, o_b2 = o_b1 + Hp + Hp * ldH, o_w3 = o_b2 + Hp, o_b3 = o_w3 + Hp;
+    __shared__ __attribute__((aligned(16))) float sm[5 * 4 * ldAH + 4 * ldAF + 64];
     const float* P = a.params;
-    const float* W1T = a.wT;
-    const float* W2T = a.wT + Fp * ldH;
+    const float* I_W1 = a.wT;                    // images (sg_thin.hpp): W1 for x W1^T, W2 for h W2^T,
+    const float* I_W2 = I_W1 + Hp * Fp;          // W2^T for d W2, W1^T for d W1
+    const float* I_W2T = I_W2 + Hp * Hp;
+    const float* I_W1T = I_W2T + Hp * Hp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 4, cl = lane & 15;
     const int col = 16 * wave + cl;
     const bool actH = wave < KH, actF = wave < KF;
+    const int wvH = actH ? wave : KH - 1, colH = 16 * wvH + cl;
     const int nb = 16 * a.G, Kt = 4 * nb, G4 = 4 * a.G;
-    float* L2s = a.ops;
-    float* R2s = L2s + (size_t)Kt * ldH;
-    float* L1s = R2s + (size_t)Kt * ldH;
-    float* R1s = L1s + (size_t)Kt * ldH;
+    const SgStacks stk = sg_disc_stacks(a.ops, Kt, Hp, Fp, ldF);
+    float* L2s = stk.L2;
+    float* R2s = stk.R2;
+    float* L1s = stk.L1;
+    float* R1s = stk.R1;     // row-major: pre-gathered input rows
+    float* R1t = stk.R1t;    // tiled: gb rows for the weight gradient
     float* part = a.part + (size_t)blockIdx.x * (4 * Hp);   // db1 | db2 | dw3 | scalars
-    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32] = clock64();
+    if (a.dbg && tid == 0) { a.dbg[blockIdx.x * 32] = clock64(); a.dbg[blockIdx.x * 32 + 28] = wall_clock64(); }
     float4 w1[SG4_NW(Fp)], w2[SG4_NW(Hp)], w2t[SG4_NW(Hp)];
     float b1c = 0.f, b2c = 0.f, w3c = 0.f;
 
-    if ((int)blockIdx.x < G4) {
-        // ------------------------------------------------ BCE group: row group 0 = 4 expert rows, 1 = 4 policy rows
-        const int bi0 = 4 * blockIdx.x;
-        const int rE0 = 32 * (bi0 >> 4) + (bi0 & 15);            // expert rows rE0+i, policy rows rE0+16+i in the stacks
-        float* H1 = sm;                 // [8][ldAH]
-        float* DZ2 = H1 + 8 * ldAH;     // [8][ldAH]
-        float* LP = DZ2 + 8 * ldAH;     // [8 waves][8 rows] logit partials
-        float4 ax[2][SG4_NCH(Fp)];
-        sg4_load_a<Fp, 2>(ax, R1s + (size_t)rE0 * ldF, ldF, lane, 16);   // pre-gathered by the previous launch
-        if (actH) {
-            sg4_load_w<Fp>(w1, P, ldF, col, lane);
-            b1c = P[o_b1 + col]; b2c = P[o_b2 + col]; w3c = P[o_w3 + col];
-            sg4_load_w<Hp>(w2, P + o_w2, ldH, col, lane);
-            sg4_load_w<Hp>(w2t, W2T, ldH, col, lane);
-        }
+    if ((int)blockIdx.x >= G4) {
+        // ------------------------------------------------ BCE group: 4 expert rows (even) or 4 policy rows (odd)
+        const int bq = blockIdx.x - G4;
+        const int bi0 = 4 * (bq >> 1);
+        const bool is_policy = bq & 1;
+        const int r0 = 32 * (bi0 >> 4) + (bi0 & 15) + (is_policy ? 16 : 0);   // this group's rows in the stacks
+        float* H1 = sm;                 // [4][ldAH]
+        float* DZ2 = H1 + 4 * ldAH;     // [4][ldAH]
+        float* LP = DZ2 + 4 * ldAH;     // [8 waves][4 rows] logit partials
+        float4 ax[1][SG4_NCH(Fp)];
+        // loads are unconditional and in consumption order (idle waves fetch a duplicate slice): memory
+        // returns in order, so the first GEMM waits for its own operands only and the later matrices land
+        // while it runs.  The scheduling barriers keep the compiler from sinking the small loads to the end.
+        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
         const float b3 = P[o_b3];
-        float h1[2] = {0.f, 0.f}, h2[2] = {0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_a<Fp, 1>(ax, R1s + (size_t)r0 * ldF, ldF, lane);   // pre-gathered by the previous launch
+        sg4_load_w<Fp>(w1, I_W1, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // every wave's W1 request is queued before anyone's W2: the first GEMM starts ~2k cycles earlier
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_w<Hp>(w2, I_W2, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_w<Hp>(w2t, I_W2T, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        float h1 = 0.f, h2 = 0.f;
         if (actH) {
-            float o[2];
-            sg4_mma<Fp, 2>(ax, w1, lane, o);
-#pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
-                h1[rg] = sg_tanh(o[rg] + b1c);
-                H1[(4 * rg + s) * ldAH + col] = h1[rg];
-                R2s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = h1[rg];
-            }
+            float o[1];
+            sg4_mma<Fp, 1>(ax, w1, lane, o);
+            h1 = sg_tanh(o[0] + b1c);
+            H1[s * ldAH + col] = h1;
+            R2s[SG_STK(Kt, r0 + s, col)] = h1;
         }
         SG_PHASE_SYNC(1);
-        if (blockIdx.x == 0 && tid == 511) sg_opt_advance(a.st);   // Adam t / bias corrections for the k_disc_wgrad that follows
         if (actH) {
-            float4 ah[2][SG4_NCH(Hp)];
-            float o[2];
-            sg4_load_a<Hp, 2>(ah, H1, ldAH, lane);
-            sg4_mma<Hp, 2>(ah, w2, lane, o);
-#pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
-                h2[rg] = sg_tanh(o[rg] + b2c);
-                const float pl = sg4_rowsum16(h2[rg] * w3c);
-                if (cl == 0) LP[wave * 8 + 4 * rg + s] = pl;
-            }
+            float4 ah[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(ah, H1, ldAH, lane);
+            sg4_mma<Hp, 1>(ah, w2, lane, o);
+            h2 = sg_tanh(o[0] + b2c);
+            const float pl = sg4_rowsum16(h2 * w3c);
+            if (cl == 0) LP[wave * 4 + s] = pl;
         }
         SG_PHASE_SYNC(2);
-        {   // logits, BCE losses and dL/dd for this lane's two rows   (a2c/algo/gail.py:168-176)
+        {   // logit, BCE loss and dL/dd of this lane's row   (a2c/algo/gail.py:168-176)
             const bool valid = bi0 + s < a.B;
-            float grad[2], loss[2];
+            float dd = b3;
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
-                float dd = b3;
-#pragma unroll
-                for (int w = 0; w < KH; ++w) dd += LP[w * 8 + 4 * rg + s];
-                loss[rg] = 0.f; grad[rg] = 0.f;
-                if (valid) {
-                    if (rg == 0) { loss[rg] = -sg_log_sigmoid(dd); grad[rg] = a.inv_B * (sg_sigmoid(dd) - 1.f); }
-                    else { loss[rg] = dd - sg_log_sigmoid(dd); grad[rg] = a.inv_B * sg_sigmoid(dd); }
-                }
+            for (int w = 0; w < KH; ++w) dd += LP[w * 4 + s];
+            // sigmoid and log-sigmoid from one exponential: e = exp(-|dd|)
+            const float e = expf(-fabsf(dd)), inv = 1.f / (1.f + e), l1p = log1pf(e);
+            const float sig = dd >= 0.f ? inv : e * inv, lsig = fminf(dd, 0.f) - l1p;
+            float loss = 0.f, grad = 0.f;
+            if (valid) {
+                if (!is_policy) { loss = -lsig; grad = a.inv_B * (sig - 1.f); }
+                else { loss = dd - lsig; grad = a.inv_B * sig; }
             }
             if (actH) {
-                float gw = 0.f, gb = 0.f;
-#pragma unroll
-                for (int rg = 0; rg < 2; ++rg) {
-                    const float dz = grad[rg] * w3c * (1.f - h2[rg] * h2[rg]);
-                    gw += grad[rg] * h2[rg];
-                    gb += dz;
-                    DZ2[(4 * rg + s) * ldAH + col] = dz;
-                    L2s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = dz;
-                }
-                gw = sg4_colsum(gw);
-                gb = sg4_colsum(gb);
+                const float dz = grad * w3c * (1.f - h2 * h2);
+                DZ2[s * ldAH + col] = dz;
+                L2s[SG_STK(Kt, r0 + s, col)] = dz;
+                const float gw = sg4_colsum(grad * h2), gb = sg4_colsum(dz);
                 if (s == 0) { part[2 * Hp + col] = gw; part[Hp + col] = gb; }
             }
             if (wave == 0) {
-                const float db3 = sg4_colsum(grad[0] + grad[1]), le = sg4_colsum(loss[0]), lp = sg4_colsum(loss[1]);
-                if (lane < 4) part[3 * Hp + lane] = lane == 0 ? db3 : lane == 1 ? le : lane == 2 ? lp : 0.f;
+                const float db3 = sg4_colsum(grad), ls = sg4_colsum(loss);
+                if (lane < 4) part[3 * Hp + lane] = lane == 0 ? db3 : (lane == 1 && !is_policy) || (lane == 2 && is_policy) ? ls : 0.f;
             }
         }
         SG_PHASE_SYNC(3);
         if (actH) {   // dZ1 = (dZ2 W2) * (1 - h1^2) straight to the left stack; db1 = its column sums
-            float4 ad[2][SG4_NCH(Hp)];
-            float o[2];
-            sg4_load_a<Hp, 2>(ad, DZ2, ldAH, lane);
-            sg4_mma<Hp, 2>(ad, w2t, lane, o);
-            float sb = 0.f;
-#pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
-                const float dz1 = o[rg] * (1.f - h1[rg] * h1[rg]);
-                L1s[(size_t)(rE0 + 16 * rg + s) * ldH + col] = dz1;
-                sb += dz1;
-            }
-            sb = sg4_colsum(sb);
+            float4 ad[1][SG4_NCH(Hp)];
+            float o[1];
+            sg4_load_a<Hp, 1>(ad, DZ2, ldAH, lane);
+            sg4_mma<Hp, 1>(ad, w2t, lane, o);
+            const float dz1 = o[0] * (1.f - h1 * h1);
+            L1s[SG_STK(Kt, r0 + s, col)] = dz1;
+            const float sb = sg4_colsum(dz1);
             if (s == 0) part[col] = sb;
         }
     } else {
         // ------------------------------------------------ mixup group: gradient penalty on 4 rows
-        const int bi0 = 4 * (blockIdx.x - G4);
+        const int bi0 = 4 * blockIdx.x;   // the longest chain: these blocks are dispatched first
         const int rowA = 2 * nb + bi0, rowB = 3 * nb + bi0;
         float* H1 = sm;               // [4][ldAH] each
         float* D2 = H1 + 4 * ldAH;
         float* D1 = D2 + 4 * ldAH;
         float* BU1 = D1 + 4 * ldAH;
         float* Z2B = BU1 + 4 * ldAH;
-        float* GX = sm + 5 * 8 * ldAH;   // [4][ldAF]
+        float* GX = sm + 5 * 4 * ldAH;   // [4][ldAF]
         float4 w1t[SG4_NW(Hp)];
         float4 ax[1][SG4_NCH(Fp)];
+        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
+        __builtin_amdgcn_sched_barrier(0);
         sg4_load_a<Fp, 1>(ax, R1s + (size_t)rowB * ldF, ldF, lane);      // pre-gathered mixup rows
-        if (actH) {
-            sg4_load_w<Fp>(w1, P, ldF, col, lane);
-            b1c = P[o_b1 + col]; b2c = P[o_b2 + col]; w3c = P[o_w3 + col];
-            sg4_load_w<Hp>(w2, P + o_w2, ldH, col, lane);
-            sg4_load_w<Hp>(w2t, W2T, ldH, col, lane);
-        }
-        if (actF) sg4_load_w<Hp>(w1t, W1T, ldH, col, lane);
+        sg4_load_w<Fp>(w1, I_W1, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // see the BCE branch
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_w<Hp>(w2, I_W2, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_w<Hp>(w2t, I_W2T, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sg4_load_w<Hp>(w1t, I_W1T, wave < KF ? wave : KF - 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
         float h1 = 0.f, h2 = 0.f, u1 = 0.f, sb1 = 0.f, gown = 0.f;
         if (actH) {
             float o[1];
             sg4_mma<Fp, 1>(ax, w1, lane, o);
             h1 = sg_tanh(o[0] + b1c);
             H1[s * ldAH + col] = h1;
-            R2s[(size_t)(rowB + s) * ldH + col] = h1;
+            R2s[SG_STK(Kt, rowB + s, col)] = h1;
         }
         SG_PHASE_SYNC(8);
         if (actH) {
@@ -520,7 +541,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
             h2 = sg_tanh(o[0] + b2c);
             const float d2 = w3c * (1.f - h2 * h2);
             D2[s * ldAH + col] = d2;
-            L2s[(size_t)(rowA + s) * ldH + col] = d2;
+            L2s[SG_STK(Kt, rowA + s, col)] = d2;
         }
         SG_PHASE_SYNC(9);
         if (actH) {   // u1 = d2 W2
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
             u1 = o[0];
             const float d1 = u1 * (1.f - h1 * h1);
             D1[s * ldAH + col] = d1;
-            L1s[(size_t)(rowA + s) * ldH + col] = d1;
+            L1s[SG_STK(Kt, rowA + s, col)] = d1;
         }
         SG_PHASE_SYNC(10);
         if (actF) {   // g = d1 W1
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
             const float nn = sqrtf(ss);
             const bool valid = bi0 + s < a.B;
             const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
-            if (actF) R1s[(size_t)(rowA + s) * ldF + col] = gown * cr;           // gb
+            if (actF) R1t[SG_STK(Kt, rowA + s, col)] = gown * cr;                // gb
             if (wave == 0) {
                 const float rl = sg4_colsum(valid ? (nn - 1.f) * (nn - 1.f) : 0.f);
                 if (lane < 4) part[3 * Hp + lane] = lane == 3 ? rl : 0.f;         // sum (|g|-1)^2
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
                 const float bd1 = o[0];
                 const float bu1 = bd1 * (1.f - h1 * h1);
                 BU1[s * ldAH + col] = bu1;
-                R2s[(size_t)(rowA + s) * ldH + col] = bu1;
+                R2s[SG_STK(Kt, rowA + s, col)] = bu1;
                 sb1 = bd1 * u1;
             }
         }
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
             const float t3 = bd2 * s2;                                   // -> dw3
             const float z2b = (-2.f * h2 * (bd2 * w3c)) * s2;
             Z2B[s * ldAH + col] = z2b;
-            L2s[(size_t)(rowB + s) * ldH + col] = z2b;
+            L2s[SG_STK(Kt, rowB + s, col)] = z2b;
             const float sw = sg4_colsum(t3), sb = sg4_colsum(z2b);
             if (s == 0) { part[2 * Hp + col] = sw; part[Hp + col] = sb; }
         }
@@ -593,23 +614,32 @@ __global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
             sg4_load_a<Hp, 1>(av, Z2B, ldAH, lane);
             sg4_mma<Hp, 1>(av, w2t, lane, o);
             const float z1b = (o[0] - 2.f * h1 * sb1) * (1.f - h1 * h1);
-            L1s[(size_t)(rowB + s) * ldH + col] = z1b;
+            L1s[SG_STK(Kt, rowB + s, col)] = z1b;
             const float sb = sg4_colsum(z1b);
             if (s == 0) part[col] = sb;
         }
     }
     SG_PHASE_SYNC(31);
+    if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32 + 29] = wall_clock64();
 }
 
-// W1^T / W2^T image for k_disc_chain4 from the padded parameter vector (after sg_disc_set_params).
-__global__ __launch_bounds__(256) void k_disc_transpose(SgDiscDesc d, const float* params, float* wT) {
-    const int n1 = d.Fp * d.ldH, n2 = d.Hp * d.ldH;
+// The four weight images of k_disc_chain4 from the padded parameter vector (after sg_disc_set_params).
+__device__ __forceinline__ void sg_disc_img_store(const SgDiscDesc& d, float* img, bool is_w2, int row, int col, float p) {
+    const int Hp = d.Hp, Fp = d.Fp;
+    if (is_w2) {
+        img[Hp * Fp + sg4_img_index(row, col, Hp)] = p;                       // W2   (n = row, k = col)
+        img[Hp * Fp + Hp * Hp + sg4_img_index(col, row, Hp)] = p;             // W2^T (n = col, k = row)
+    } else {
+        img[sg4_img_index(row, col, Fp)] = p;                                 // W1
+        img[Hp * Fp + 2 * Hp * Hp + sg4_img_index(col, row, Hp)] = p;         // W1^T
+    }
+}
+__global__ __launch_bounds__(256) void k_disc_images(SgDiscDesc d, const float* params, float* img) {
+    const int n1 = d.Hp * d.Fp, n2 = d.Hp * d.Hp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
-        const bool one = i < n1;
-        const int j = one ? i : i - n1, r = j / d.ldH, c = j % d.ldH;
-        float v = 0.f;
-        if (c < d.Hp) v = one ? params[d.w1 + c * d.ldF + r] : params[d.w2 + c * d.ldH + r];
-        wT[i] = v;
+        const bool w2 = i >= n1;
+        const int j = w2 ? i - n1 : i, nc = w2 ? d.Hp : d.Fp, r = j / nc, c = j % nc;
+        sg_disc_img_store(d, img, w2, r, c, params[(w2 ? d.w2 : d.w1) + r * (w2 ? d.ldH : d.ldF) + c]);
     }
 }
 
@@ -626,7 +656,9 @@ struct WgradArgs {
     double* loss_acc;
     PregatherArgs next;       // next step's inputs (next.ops == NULL on the last step)
     int nparts;               // workgroups of the chain kernel (rows of `part`)
-    float* wT;                // transposed weight image to keep in step (NULL: not maintained)
+    int t;                    // Adam step number of this launch (1-based); its scalars sit in slot t & 1 of *st
+    float* wT;                // k_disc_chain4's weight images to keep in step (NULL: not maintained)
+    long long* dbg;           // optional wall-clock stamps per block (test hook), NULL in production
 };
 
 // torch.optim.Adam single-tensor math (a2c/algo/gail.py:48,186-188: lr 1e-3, eps 1e-8)
@@ -651,11 +683,17 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
     const int th = d.Hp >> 4, tf = d.Fp >> 4;
     const int T2 = th * th, T1 = th * tf;
     const int Kt = 64 * a.G;
-    const int b = blockIdx.x;
-    if (b > T2 + T1) {   // blocks past the tiles and the vector block: prepare the next step's rows
-        if (a.next.ops) sg_disc_pregather(a.next, b - (T2 + T1 + 1));
+    // test hook: wall clock (100 MHz) at block start / after the operand loads / after the LDS reduce / end
+    long long* stamp = (a.dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
+    if (stamp) stamp[0] = wall_clock64();
+    // the first 2G blocks prepare the next step (two dependent global round trips: index, then row): they are
+    // dispatched first so they finish with the tiles; one lane also evaluates the next step's Adam scalars
+    if ((int)blockIdx.x < 2 * a.G) {
+        if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.t + 1);
+        if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
         return;
     }
+    const int b = blockIdx.x - 2 * a.G;
     if (b < T2 + T1) {
         const bool w2 = b < T2;
         const int t = w2 ? b : b - T2;
@@ -663,13 +701,17 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         const int ldp = w2 ? d.ldH : d.ldF;
         // the tile's 256 parameters and moments: requested first so they arrive with the operands
         const int idx = (w2 ? d.w2 : d.w1) + (tm * 16 + ((tid & 255) >> 4)) * ldp + tn * 16 + (tid & 15);
-        float p0 = 0.f, m0 = 0.f, v0 = 0.f;
-        if (tid < 256 && !a.grad_out) { p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }
-        const float* L = a.ops + (w2 ? (size_t)0 : (size_t)2 * Kt * d.ldH);
-        const float* Rr = w2 ? a.ops + (size_t)Kt * d.ldH : a.ops + (size_t)3 * Kt * d.ldH;
-        const int ldr = w2 ? d.ldH : d.ldF;
-        // this wave's slice of the stacked rows (Kt / 8 = 8*G rows: a multiple of 16 for even G; the
-        // general case walks 16-row chunks dealt round-robin to waves)
+        float p0 = 0.f, m0 = 0.f, v0 = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
+        if (tid < 256 && !a.grad_out) {
+            p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx];
+            step_size = a.st->step_size2[a.t & 1]; bc2_sqrt = a.st->bc2_sqrt2[a.t & 1];
+        }
+        const SgStacks stk = sg_disc_stacks(const_cast<float*>(a.ops), Kt, d.Hp, d.Fp, d.ldF);
+        // the two [Kt x 16] slabs this tile contracts: contiguous in the tiled stacks
+        const float* L = (w2 ? stk.L2 : stk.L1) + (size_t)tm * Kt * 16;
+        const float* Rr = (w2 ? stk.R2 : stk.R1t) + (size_t)tn * Kt * 16;
+        // waves split the stacked rows in 16-row chunks dealt round-robin; within a chunk MFMA step s takes
+        // rows 4s..4s+3 (k = lq), so one load instruction of a wave covers 256 contiguous bytes
         const int n_chunks = Kt >> 4;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, alt = acc;
         for (int c0 = wave; c0 < n_chunks; c0 += 4 * nw) {       // up to 4 chunks = 32 loads in flight per lane
@@ -679,10 +721,10 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int c = c0 + cc * nw;
-                    const int r = 16 * c + 4 * lq + s;
+                    const int r = 16 * c + 4 * s + lq;
                     const bool in = c < n_chunks;
-                    x[cc][s] = in ? L[(size_t)r * d.ldH + tm * 16 + li] : 0.f;
-                    y[cc][s] = in ? Rr[(size_t)r * ldr + tn * 16 + li] : 0.f;
+                    x[cc][s] = in ? L[(size_t)r * 16 + li] : 0.f;
+                    y[cc][s] = in ? Rr[(size_t)r * 16 + li] : 0.f;
                 }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
@@ -695,13 +737,14 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         acc += alt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(4 * lq + r) * 16 + li] = acc[r];
+        if (stamp) stamp[1] = wall_clock64();
         __syncthreads();
+        if (stamp) stamp[2] = wall_clock64();
         if (tid < 256) {
             float g = 0.f;
             for (int w = 0; w < nw; ++w) g += red[w][tid];
             if (a.grad_out) a.grad_out[idx] = g;
             else {
-                const float step_size = a.st->step_size, bc2_sqrt = a.st->bc2_sqrt;
                 m0 = m0 + (g - m0) * (float)(1.0 - 0.9);
                 v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
                 const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
@@ -711,40 +754,51 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
                 a.v[idx] = v0;
             }
         }
-        if (a.wT && !a.grad_out) {   // the tile's transpose, through LDS so both images are written in 64-byte runs
-            __syncthreads();
-            if (tid < 256) red[0][tid] = p0;
-            __syncthreads();
-            if (tid < 256) {
-                float* T = a.wT + (w2 ? (size_t)d.Fp * d.ldH : (size_t)0);
-                T[(size_t)(tn * 16 + (tid >> 4)) * d.ldH + tm * 16 + (tid & 15)] = red[0][(tid & 15) * 16 + (tid >> 4)];
+        if (a.wT && !a.grad_out && tid < 256) sg_disc_img_store(d, a.wT, w2, tm * 16 + (tid >> 4), tn * 16 + (tid & 15), p0);
+        if (stamp) stamp[3] = wall_clock64();
+    } else {
+        // vectors: db1 | db2 | dw3 | db3 and the three loss sums from the per-workgroup partials.  Vector block vb
+        // owns elements [64 vb, 64 vb + 64); its 8 waves each sum an eighth of the partials (independent
+        // loads, 4 in flight per lane), then combine through LDS.
+        const int Hp = d.Hp, nparts = a.nparts, stride = 4 * Hp, NE = 3 * Hp + 4;
+        const int i = 64 * (b - (T2 + T1)) + lane;
+        const float step_size = a.st->step_size2[a.t & 1], bc2_sqrt = a.st->bc2_sqrt2[a.t & 1];
+        float g = 0.f;
+        if (i < NE) {
+            for (int s0 = wave; s0 < nparts; s0 += 16 * nw) {   // 16 loads in flight per lane: one round trip at batch 128
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int sidx = s0 + u * nw;
+                    t[u] = sidx < nparts ? a.part[(size_t)sidx * stride + i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) g += t[u];
             }
         }
-    } else {
-        // vectors: db1 | db2 | dw3 | db3 from the per-workgroup partials, and the loss sums
-        const float step_size = a.st->step_size, bc2_sqrt = a.st->bc2_sqrt;
-        const int Hp = d.Hp, nparts = a.nparts, stride = 4 * Hp;
-        for (int i = tid; i < 3 * Hp + 4; i += blockDim.x) {
-            float g = 0.f;
-            for (int s = 0; s < nparts; ++s) g += a.part[(size_t)s * stride + i];
+        red[wave][lane] = g;
+        __syncthreads();
+        if (wave == 0 && i < NE) {
+            g = 0.f;
+            for (int w = 0; w < nw; ++w) g += red[w][lane];
             if (i < 3 * Hp + 1) {
                 const int idx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
                 if (a.grad_out) a.grad_out[idx] = g;
                 else sg_adam_apply(a.params + idx, a.m + idx, a.v + idx, g, step_size, bc2_sqrt, a.eps);
-            } else {
-                red[0][i - (3 * Hp + 1)] = g;       // loss_expert, loss_policy, loss_gp sums
             }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (a.grad_out) {
-                a.grad_out[d.total + 0] = red[0][0]; a.grad_out[d.total + 1] = red[0][1]; a.grad_out[d.total + 2] = red[0][2];
-            } else {
-                // a2c/algo/gail.py:181-184: loss.item() etc. are float32, accumulated in Python doubles
-                const float el = red[0][0] * a.inv_B, pl = red[0][1] * a.inv_B, gp = a.lambda_ * (red[0][2] * a.inv_B);
-                a.loss_acc[0] += (double)(el + pl + gp);
-                a.loss_acc[1] += (double)el;
-                a.loss_acc[2] += (double)pl;
+            // loss_expert, loss_policy, loss_gp sums sit in elements 3Hp+1..3 = lanes l0+1..l0+3 of the last block
+            const int l0 = (3 * Hp) & 63;
+            const float el_s = __shfl(g, l0 + 1), pl_s = __shfl(g, l0 + 2), gp_s = __shfl(g, l0 + 3);
+            if (i == 3 * Hp) {
+                if (a.grad_out) {
+                    a.grad_out[d.total + 0] = el_s; a.grad_out[d.total + 1] = pl_s; a.grad_out[d.total + 2] = gp_s;
+                } else {
+                    // a2c/algo/gail.py:181-184: loss.item() etc. are float32, accumulated in Python doubles
+                    const float el = el_s * a.inv_B, pl = pl_s * a.inv_B, gp = a.lambda_ * (gp_s * a.inv_B);
+                    a.loss_acc[0] += (double)(el + pl + gp);
+                    a.loss_acc[1] += (double)el;
+                    a.loss_acc[2] += (double)pl;
+                }
             }
         }
     }
@@ -753,13 +807,13 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
 // Data-parallel mode only: Adam from the all-reduced flat gradient (+ loss sums in its tail).
 __global__ __launch_bounds__(256) void k_disc_adam_flat(float* params, float* m, float* v, const float* grad, int total,
                                                         const SgOptState* st, float eps, float inv_B, float lambda_,
-                                                        double* loss_acc, SgDiscDesc d, float* wT) {
+                                                        double* loss_acc, SgDiscDesc d, float* wT, int t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size, st->bc2_sqrt, eps);
+        sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size2[t & 1], st->bc2_sqrt2[t & 1], eps);
         if (wT) {
-            if (i < d.b1) { const int r = i / d.ldF, c = i % d.ldF; if (c < d.Fp) wT[c * d.ldH + r] = params[i]; }
-            else if (i >= d.w2 && i < d.b2) { const int j = i - d.w2, r = j / d.ldH, c = j % d.ldH; if (c < d.Hp) wT[(d.Fp + c) * d.ldH + r] = params[i]; }
+            if (i < d.b1) { const int r = i / d.ldF, c = i % d.ldF; if (c < d.Fp) sg_disc_img_store(d, wT, false, r, c, params[i]); }
+            else if (i >= d.w2 && i < d.b2) { const int j = i - d.w2, r = j / d.ldH, c = j % d.ldH; if (c < d.Hp) sg_disc_img_store(d, wT, true, r, c, params[i]); }
         }
     }
     if (i == 0) {

@@ -46,11 +46,15 @@ __global__ __launch_bounds__(512) void k_thin_test(GemmTestArgs a) {
     float4 w[SG4_NW(K)];
     float4 x[RG][SG4_NCH(K)];
     float out[RG];
-    sg4_load_w<K>(w, a.B, K, 16 * wave + (lane & 15), lane);
+    sg4_load_w<K>(w, a.B, wave, lane);   // a.B is the image built by k_thin_swizzle
     sg4_load_a<K, RG>(x, a.A, K, lane);
     sg4_mma<K, RG>(x, w, lane, out);
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) a.C[(size_t)(4 * rg + (lane >> 4)) * a.N + 16 * wave + (lane & 15)] = out[rg];
+}
+
+__global__ void k_thin_swizzle(const float* M, int N, int K, float* img) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * K; i += gridDim.x * blockDim.x) img[sg4_img_index(i / K, i % K, K)] = M[i];
 }
 
 template <int K>
@@ -97,7 +101,10 @@ extern "C" int sg_test_gemm(sg_ctx* ctx, int mode, int M, int N, int K, const fl
         SG_CHECK(hipMalloc((void**)&dC, sizeof(float) * M * N));
         SG_CHECK(hipMemcpy(dA, A, sizeof(float) * M * K, hipMemcpyHostToDevice));
         SG_CHECK(hipMemcpy(dB, B, sizeof(float) * N * K, hipMemcpyHostToDevice));
-        GemmTestArgs a{mode, M, N, K, dA, dB, dC};
+        float* dImg;
+        SG_CHECK(hipMalloc((void**)&dImg, sizeof(float) * N * K));
+        hipLaunchKernelGGL(k_thin_swizzle, dim3(16), dim3(256), 0, ctx->stream, dB, N, K, dImg);
+        GemmTestArgs a{mode, M, N, K, dA, dImg, dC};
         if (K == 16) launch_thin_test<16>(ctx, a);
         else if (K == 32) launch_thin_test<32>(ctx, a);
         else if (K == 96) launch_thin_test<96>(ctx, a);
@@ -105,7 +112,7 @@ extern "C" int sg_test_gemm(sg_ctx* ctx, int mode, int M, int N, int K, const fl
         SG_CHECK(hipGetLastError());
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         SG_CHECK(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
-        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dImg);
         return 0;
     }
     SG_REQUIRE(mode >= 0 && mode <= 2, "sg_test_gemm: mode must be 0 (NT), 1 (NN), 2 (TN) or 3 (thin NT)");

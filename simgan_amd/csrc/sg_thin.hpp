@@ -26,14 +26,22 @@ __device__ __forceinline__ f32x4 sg4_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, ABID, 0);
 }
 
-// This lane's B operand for the whole kernel: row n of the row-major matrix M (leading dimension
-// ld floats, a multiple of 4), K slice s.  M[n][k] multiplies in[.][k]: for y = x W^T pass W, for
-// y = d W pass the stored transpose of W.
+// Weight images.  A matrix M[n][k] (n < 16*waves, K a multiple of 16) that multiplies in[.][k] is
+// kept in global memory in the order the lanes consume it: float4 number ((n>>4)*K/16 + t)*64 + lane
+// holds M[n][s*K/4 + 4t .. +3] for lane = 16 s + (n & 15).  One load instruction of a wave is then one
+// contiguous KiB (8 cache lines) instead of 64 scattered 16-byte pieces.  For y = x W^T the image is
+// built from W, for y = d W from W^T; k_disc_wgrad writes both images next to the canonical layout.
+__host__ __device__ __forceinline__ int sg4_img_index(int n, int k, int K) {
+    const int KS = K / 4, s = k / KS, ko = k - s * KS;
+    return ((((n >> 4) * (K / 16) + (ko >> 2)) * 64 + 16 * s + (n & 15)) << 2) + (ko & 3);
+}
+
+// This lane's B operand for the whole kernel: wave-th 16-column slice of an image.
 template <int K>
-__device__ __forceinline__ void sg4_load_w(float4 (&w)[SG4_NW(K)], const float* M, int ld, int n, int lane) {
-    const float4* p = reinterpret_cast<const float4*>(M + (size_t)n * ld + (lane >> 4) * (K / 4));
+__device__ __forceinline__ void sg4_load_w(float4 (&w)[SG4_NW(K)], const float* img, int wave, int lane) {
+    const float4* p = reinterpret_cast<const float4*>(img) + (size_t)wave * SG4_NW(K) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < SG4_NW(K); ++t) w[t] = p[t];
+    for (int t = 0; t < SG4_NW(K); ++t) w[t] = p[t * 64];
 }
 
 // A operand of RG row groups from X (LDS or global, leading dimension ldx, 16-byte aligned rows).
@@ -77,30 +85,40 @@ __device__ __forceinline__ void sg4_mma(const float4 (&a)[RG][SG4_NCH(K)], const
         SG4_STEP(2)
         SG4_STEP(3)
     }
-    const int s = lane >> 4;
+    // Sum the four K slices (lanes l, l^16, l^32, l^48) and leave row (lane >> 4) in each lane, with three
+    // cross-lane swaps on the VALU instead of eight LDS permutes: after the 32-lane swap the lower half
+    // carries rows 0/1 and the upper half rows 2/3; the 16-lane row swap finishes both sums at once.
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
-        f32x4 v = acc[rg][0] + acc[rg][1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] += __shfl_xor(v[r], 16);
-            v[r] += __shfl_xor(v[r], 32);
-        }
-        out[rg] = s == 0 ? v[0] : s == 1 ? v[1] : s == 2 ? v[2] : v[3];
+        const f32x4 v = acc[rg][0] + acc[rg][1];
+        const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+        const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+        const float e = __uint_as_float(p02[0]) + __uint_as_float(p02[1]);   // [row0 | row2] summed over s, s^2
+        const float o = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);   // [row1 | row3]
+        const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
+        out[rg] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
     }
+    (void)lane;
 }
 
-// sum of one value per lane over the four K-slice lanes that hold the four rows of a column
+// sum of one value per lane over the four K-slice lanes (l, l^16, l^32, l^48) that hold the four rows of a
+// column: two VALU lane swaps (upper/lower half, then odd/even 16-lane rows), result in all four lanes
 __device__ __forceinline__ float sg4_colsum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
-// sum over the 16 lanes that hold one row's 16 columns of this wave
+// sum over the 16 lanes (one DPP row) that hold one row's 16 columns of this wave, result in all 16 lanes:
+// quad butterflies, then the half-row and row mirrors (every lane of a quad already holds the quad's sum)
+template <int CTRL>
+__device__ __forceinline__ float sg4_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float sg4_rowsum16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v = sg4_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = sg4_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = sg4_dpp_add<0x141>(v);   // row_half_mirror
+    v = sg4_dpp_add<0x140>(v);   // row_mirror
     return v;
 }

@@ -1,4 +1,4 @@
-"""Per-phase shader-clock breakdown of k_disc_grad (test hook sg_test_disc_phase_times).
+"""Per-phase shader-clock breakdown of k_disc_chain4 / k_disc_chain (test hook sg_test_disc_phase_times).
 Run on the GPU box:  python tools/phase_times.py"""
 import ctypes as C
 import os
@@ -21,14 +21,32 @@ fn.argtypes = [_lib.H, C.c_int, C.POINTER(C.c_longlong), C.c_int]
 disc.update_gail_dyn(loader, ro)  # warm
 _lib.check(fn(disc.h, 1, None, 0))
 disc.update_gail_dyn(loader, ro)
-nb = 2 * ((w["B"] + 15) // 16)
+thin = os.environ.get("SG_DISC_CHAIN", "thin") != "wide"
+nb = (12 if thin else 2) * ((w["B"] + 15) // 16)
 buf = (C.c_longlong * (32 * nb))()
 _lib.check(fn(disc.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 32)
-for name, b in (("BCE block 0", 0), ("mix block", nb // 2)):
+for name, b in ((("mix block 0", 0), ("mix block 9", 9), ("BCE block", nb // 3 + 5)) if thin else (("BCE block 0", 0), ("mix block", nb // 2))):
     row = t[b]
-    idx = [i for i in range(32) if row[i] != 0]
+    idx = [i for i in range(32) if row[i] != 0 and i not in (28, 29)]
     print(name, "total cycles", row[idx[-1]] - row[idx[0]])
     for i0, i1 in zip(idx[:-1], idx[1:]):
         print(f"   phase {i0:2d}->{i1:2d}: {row[i1] - row[i0]:8d} cycles")
+# wall-clock (100 MHz) timeline of the LAST step of the epoch: chain blocks, then k_disc_wgrad blocks by role
+full = (C.c_longlong * (32 * 512))()
+_lib.check(fn(disc.h, 1, full, 512))
+f = np.array(full, dtype=np.int64).reshape(512, 32)
+cs, ce = f[:nb, 28], f[:nb, 29]
+t0 = cs.min()
+print(f"chain: blocks start {10 * (cs.min() - t0)}..{10 * (cs.max() - t0)} ns, end {10 * (ce.min() - t0)}..{10 * (ce.max() - t0)} ns")
+wg = f[256:].reshape(-1)[: 4 * 400].reshape(400, 4)
+G = (w["B"] + 15) // 16
+kf, kh = (w["F"] + 15) // 16, (w["Hd"] + 15) // 16
+nt, nv = kh * kh + kh * kf, (3 * 16 * kh + 4 + 63) // 64
+st = wg[:, 0]
+print(f"wgrad: all blocks start {10 * (st[:2 * G + nt + nv].min() - t0)}..{10 * (st[:2 * G + nt + nv].max() - t0)} ns after the chain's first block")
+tl = wg[2 * G:2 * G + nt]
+for nm, k in (("operands loaded + MFMA", 1), ("LDS reduce barrier", 2), ("Adam + stores issued", 3)):
+    dt = 10 * (tl[:, k] - tl[:, 0])
+    print(f"wgrad tiles: {nm:24s} at +{dt.min()}..{dt.max()} ns (median {int(np.median(dt))})")
 _lib.check(fn(disc.h, 0, None, 0))
