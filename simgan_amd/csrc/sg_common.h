@@ -102,10 +102,17 @@ struct sg_ctx {
     size_t scratch_bytes = 0;
     void* h_pinned = nullptr;     // pinned host staging
     size_t pinned_bytes = 0;
+    double* mailbox = nullptr;    // 2 x 64 doubles of device-visible pinned host memory: small results / small inputs
 };
 
 int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out);
 int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out);
+// n <= 64 doubles device -> host / host -> device through the mailbox: a kernel reads or writes pinned host
+// memory directly, so the 24-byte loss read-backs at the end of every update phase do not go through the
+// runtime's DMA copy path (which costs tens of microseconds and occasionally stalls for milliseconds).
+// fetch synchronises the stream; put is asynchronous but ordered (it synchronises before reusing the slot).
+int sg_ctx_fetch_f64(sg_ctx* ctx, const double* dev, double* host, int n);
+int sg_ctx_put_f64(sg_ctx* ctx, double* dev, const double* host, int n);
 // Profiling: when ctx->profile is on, a launch is given a start/stop event pair through
 // hipExtLaunchKernelGGL, which timestamps the kernel's own begin and end on the device (the same
 // quantity rocprofv3 --kernel-trace reports), not the gaps around it.  Off: null events.
@@ -113,10 +120,14 @@ struct SgEv { hipEvent_t a = nullptr, b = nullptr; };
 SgEv sg_prof_events(sg_ctx* ctx, int which);
 #ifdef __HIPCC__
 #include <hip/hip_ext.h>
-#define SG_LAUNCH(ctx, which, kernel, grid, block, lds, ...)                                              \
-    do {                                                                                                  \
-        SgEv _ev = sg_prof_events(ctx, which);                                                            \
-        hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, _ev.a, _ev.b, 0, __VA_ARGS__);     \
+#define SG_LAUNCH(ctx, which, kernel, grid, block, lds, ...)                                                  \
+    do {                                                                                                      \
+        if ((ctx)->profile) {                                                                                 \
+            SgEv _ev = sg_prof_events(ctx, which);                                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, _ev.a, _ev.b, 0, __VA_ARGS__);     \
+        } else {                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);                         \
+        }                                                                                                     \
     } while (0)
 #endif
 
@@ -139,6 +150,7 @@ struct sg_rollout {
 };
 
 struct sg_ppo {
+    uint64_t scratch_key = 0;    // layout the scratch buffers were last cleared for
     sg_ctx* ctx;
     sg_policy* policy;
     sg_ppo_config cfg;
@@ -170,7 +182,9 @@ struct sg_disc {
     int64_t alpha_cap = 0;
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
-    int64_t opt_t = 0;             // completed Adam steps (the device only sees per-step scalars)
+    int64_t opt_t = 0;             // completed Adam steps (mirrors SgOptState::t0 on the device)
+    hipGraphExec_t epoch_graph = nullptr;   // one epoch of update steps, captured once and replayed
+    uint64_t epoch_graph_key[12] = {0};
     float* d_wT = nullptr;         // weight images W1 | W2 | W2^T | W1^T of k_disc_chain4, maintained by k_disc_wgrad
     float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
     int64_t rows_cap = 0;
@@ -193,9 +207,15 @@ struct SgOptState {
     // the previous optimizer kernel (sg_opt_prepare) so nothing on the step's critical path evaluates pow()
     float step_size2[2];
     float bc2_sqrt2[2];
-};
+    int t0;           // discriminator: Adam steps completed before the current epoch (k_opt_commit adds an epoch's
+    int pad[3];       // steps at its end), so per-step kernel arguments do not change between epochs and the
+};                    // epoch's launches can be replayed as a hipGraph
 
 #ifdef __HIPCC__
+// tiny clears stay on the library's own launch path (the runtime's fill path is a separate blit kernel)
+__attribute__((unused)) static __global__ void k_zero_f64(double* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.0;
+}
 // t += 1 and the bias-correction scalars of torch.optim.Adam (Python doubles in torch); called by
 // ONE thread of the kernel that precedes the Adam kernel, so the Adam kernel only reads them.
 __device__ __forceinline__ void sg_opt_advance(SgOptState* st) {

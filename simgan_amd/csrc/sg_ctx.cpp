@@ -25,6 +25,9 @@ extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     // is a PCIe round trip otherwise.  Must be in the environment before the HIP runtime
     // initialises; an explicit user setting wins.
     setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+    // Small copies on shader blits rather than the SDMA engines: an update ends each phase with a few
+    // tiny read-backs, and on this platform SDMA scheduling intermittently adds milliseconds to them.
+    setenv("HSA_ENABLE_SDMA", "0", 0);
     int count = 0;
     SG_CHECK(hipGetDeviceCount(&count));
     SG_REQUIRE(device >= 0 && device < count, "sg_ctx_create: device %d out of range (%d visible)", device, count);
@@ -38,6 +41,7 @@ extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     SG_REQUIRE(strstr(prop.gcnArchName, "gfx950") != nullptr,
                "sg_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     SG_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SG_CHECK(hipHostMalloc((void**)&ctx->mailbox, sizeof(double) * 128, hipHostMallocDefault));
     *out = ctx;
     return 0;
 }
@@ -51,8 +55,31 @@ extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return 0;
+}
+
+__global__ void k_copy_f64(double* dst, const double* src, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+int sg_ctx_fetch_f64(sg_ctx* ctx, const double* dev, double* host, int n) {
+    SG_REQUIRE(n >= 0 && n <= 64, "sg_ctx_fetch_f64: at most 64 values");
+    hipLaunchKernelGGL(k_copy_f64, dim3(1), dim3(64), 0, ctx->stream, ctx->mailbox, dev, n);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->mailbox, sizeof(double) * n);
+    return 0;
+}
+
+int sg_ctx_put_f64(sg_ctx* ctx, double* dev, const double* host, int n) {
+    SG_REQUIRE(n >= 0 && n <= 64, "sg_ctx_put_f64: at most 64 values");
+    SG_CHECK(hipStreamSynchronize(ctx->stream));   // a previous put may still be reading the slot
+    memcpy(ctx->mailbox + 64, host, sizeof(double) * n);
+    hipLaunchKernelGGL(k_copy_f64, dim3(1), dim3(64), 0, ctx->stream, dev, ctx->mailbox + 64, n);
+    SG_CHECK(hipGetLastError());
     return 0;
 }
 

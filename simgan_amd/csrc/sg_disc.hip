@@ -63,9 +63,13 @@ static bool disc_chain_thin(const SgDiscDesc& dd) {
 static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, const DiscArgs& a) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     const dim3 block(512);
-    if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<6, 7>), grid, block, 0, a);
-    else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<2, 7>), grid, block, 0, a);
-    else SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<1, 1>), grid, block, 0, a);
+#define SG_CHAIN4(KF_, KH_)                                                                                         \
+    SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<KF_, KH_>), grid, block, 0, a.params, a.wT, a.ops, a.part, a.dbg, \
+              a.B, a.G, a.inv_B, a.lambda_)
+    if (kf == 6 && kh == 7) SG_CHAIN4(6, 7);
+    else if (kf == 2 && kh == 7) SG_CHAIN4(2, 7);
+    else SG_CHAIN4(1, 1);
+#undef SG_CHAIN4
 }
 static void disc_refresh_images(sg_disc* d) {
     hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
@@ -228,6 +232,7 @@ extern "C" int sg_disc_destroy(sg_disc* d) {
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
     if (d->d_loss_acc) (void)hipFree(d->d_loss_acc);
+    if (d->epoch_graph) (void)hipGraphExecDestroy(d->epoch_graph);
     delete d;
     return 0;
 }
@@ -279,8 +284,10 @@ extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int6
     SG_REQUIRE(d && m && v, "sg_disc_set_adam: NULL argument");
     SG_TRY(disc_put(d, d->d_m, m, n, "sg_disc_set_adam"));
     SG_TRY(disc_put(d, d->d_v, v, n, "sg_disc_set_adam"));
-    SG_REQUIRE(step >= 0, "sg_disc_set_adam: negative step");
+    SG_REQUIRE(step >= 0 && step < (1ll << 30), "sg_disc_set_adam: step out of range");
     d->opt_t = step;
+    const int t0 = (int)step;
+    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(d->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -373,7 +380,6 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         // ld-padding entries of the flat gradient are never written by k_disc_wgrad: they must read as zero
         SG_CHECK(hipMemsetAsync(d->d_slabs, 0, sizeof(float) * (2 * ops_f + part_f + grad_f), ctx->stream));
     }
-    SG_CHECK(hipMemsetAsync(d->d_loss_acc, 0, sizeof(double) * 3, ctx->stream));
 
     DiscArgs a;
     a.d = dd; a.params = d->d_params; a.expert = d->d_expert;
@@ -397,39 +403,70 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int n_vec = (3 * dd.Hp + 4 + 63) / 64;
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < n_d; ++k) {
-        // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
-        const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
-        a.eperm = d->d_eperm + (size_t)k * batch_size + roff;
-        a.alpha = d->d_alpha + (size_t)k * batch_size + roff;
-        a.pperm = d->d_pperm + (size_t)k * B_loc;
-        a.ops = stacks[k & 1];
-        wa.ops = a.ops;
-        PregatherArgs pg;
-        pg.expert = d->d_expert; pg.next_feat = a.next_feat; pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp;
-        pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st; pg.t = (int)(d->opt_t + k + 1);
-        wa.t = pg.t;
-        if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
-            pg.eperm = a.eperm; pg.pperm = a.pperm; pg.alpha = a.alpha; pg.ops = a.ops;
-            hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
+    // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit
+    // the step count.  No argument of these ~2 n_d launches depends on anything but buffer addresses and the
+    // batch geometry (the Adam step number lives on the device), so the sequence is captured into a hipGraph
+    // once and replayed: the host then issues one call per epoch instead of a thousand, and a descheduled
+    // host thread can no longer starve the GPU in the middle of an epoch.
+    auto enqueue_epoch = [&]() -> int {
+        hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, ctx->stream, d->d_loss_acc, 3);
+        for (int k = 0; k < n_d; ++k) {
+            // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
+            const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
+            a.eperm = d->d_eperm + (size_t)k * batch_size + roff;
+            a.alpha = d->d_alpha + (size_t)k * batch_size + roff;
+            a.pperm = d->d_pperm + (size_t)k * B_loc;
+            a.ops = stacks[k & 1];
+            wa.ops = a.ops;
+            PregatherArgs pg;
+            pg.expert = d->d_expert; pg.next_feat = a.next_feat; pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp;
+            pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st;
+            wa.k1 = k + 1;
+            if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
+                pg.eperm = a.eperm; pg.pperm = a.pperm; pg.alpha = a.alpha; pg.ops = a.ops;
+                hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
+            }
+            pg.eperm = a.eperm + batch_size; pg.alpha = a.alpha + batch_size; pg.pperm = a.pperm + B_loc;
+            pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
+            wa.next = pg;
+            if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
+            else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
+            SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + n_vec + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
+            if (sharded) {
+                SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
+                hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
+                                   dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT, wa.k1);
+            }
         }
-        pg.eperm = a.eperm + batch_size; pg.alpha = a.alpha + batch_size; pg.pperm = a.pperm + B_loc;
-        pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
-        wa.next = pg;
-        if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
-        else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
-        SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + n_vec + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
-        if (sharded) {
-            SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
-            hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,
-                               dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT, wa.t);
+        hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, a.st, n_d);
+        return 0;
+    };
+    const char* genv = getenv("SG_DISC_GRAPH");
+    const bool use_graph = !sharded && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
+    if (!use_graph) {
+        SG_TRY(enqueue_epoch());
+    } else {
+        const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
+                                  (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
+                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin, (uint64_t)ops_f, 0x5647ull};
+        if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
+            if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
+            hipGraph_t graph = nullptr;
+            SG_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_epoch();
+            const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+            SG_REQUIRE(rc == 0, "sg_disc_update_gail_dyn: launch failed during graph capture");
+            SG_CHECK(ce);
+            SG_CHECK(hipGraphInstantiate(&d->epoch_graph, graph, nullptr, nullptr, 0));
+            SG_CHECK(hipGraphDestroy(graph));
+            memcpy(d->epoch_graph_key, key, sizeof key);
         }
+        SG_CHECK(hipGraphLaunch(d->epoch_graph, ctx->stream));
     }
     SG_CHECK(hipGetLastError());
     const auto t_enq1 = std::chrono::steady_clock::now();
     double acc[3];
-    SG_CHECK(hipMemcpyAsync(acc, d->d_loss_acc, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
-    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_TRY(sg_ctx_fetch_f64(ctx, d->d_loss_acc, acc, 3));
     if (dbg_timing) {
         const auto t_done = std::chrono::steady_clock::now();
         fprintf(stderr, "[sg] disc epoch: %d steps, enqueue %.3f ms, enqueue->done %.3f ms\n", n_d,
@@ -552,7 +589,7 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     double* stats = reinterpret_cast<double*>(scratch + ((TN + 3) & ~(int64_t)3));
     double* rms = stats + 2 * (size_t)T;
     float* scale = reinterpret_cast<float*>(rms + 4);
-    SG_CHECK(hipMemcpyAsync(rms, rms_state, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
+    SG_TRY(sg_ctx_put_f64(ctx, rms, rms_state, 3));
     float* rewards = r->d_field[SG_F_REWARDS];
     // rewards[t] <- D(obs_feat[t+1]) (+offset): rows t*N+n of obs_feat[1:]
     SG_TRY(disc_forward_dev(d, r->d_field[SG_F_OBS_FEAT] + (size_t)N * r->F, (int)TN, offset, rewards));
@@ -567,8 +604,7 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(1), 0, ctx->stream, stats, T, n_global, rms, scale);
     hipLaunchKernelGGL(k_normalize_rewards, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, ctx->stream, rewards, scale, T, N);
     SG_CHECK(hipGetLastError());
-    SG_CHECK(hipMemcpyAsync(rms_state, rms, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
-    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_TRY(sg_ctx_fetch_f64(ctx, rms, rms_state, 3));
     return 0;
 }
 

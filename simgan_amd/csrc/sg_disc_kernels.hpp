@@ -106,8 +106,7 @@ struct PregatherArgs {
     const float* alpha;
     float* ops;     // operand stacks of the step being prepared
     int B, G, F, Fp, ldF, Hp;
-    SgOptState* st; // Adam scalars of step t are prepared alongside (one lane)
-    int t;
+    SgOptState* st; // the first step's Adam scalars are prepared alongside (one lane of k_disc_pregather)
 };
 
 __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j) {
@@ -148,7 +147,7 @@ __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j)
 }
 
 __global__ __launch_bounds__(512) void k_disc_pregather(PregatherArgs p) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) sg_opt_prepare(p.st, p.t);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sg_opt_prepare(p.st, p.st->t0 + 1);
     sg_disc_pregather(p, blockIdx.x);
 }
 
@@ -392,8 +391,20 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 //   k_disc_chain the step uses 4x the CUs and a phase costs 28 MFMA issues per wave instead of 56
 //   16x16x4 issues (4x the cycles each).  Operand stacks, partials and math are identical.
 //   Requires compile-time KF, KH <= 8 (one wave per 16 columns, 8 waves).
+// Arguments are individual scalars / pointers (14 dwords), not a struct: the code object asks the command
+// processor to preload them into SGPRs (-amdgpu-kernarg-preload-count), so the first global loads do not wait
+// for a kernarg fetch from memory (~1 us after a fresh launch).
+struct Chain4Args {
+    const float *params, *wT;
+    float *ops, *part;
+    long long* dbg;
+    int B, G;
+    float inv_B, lambda_;
+};
 template <int KF, int KH>
-__global__ __launch_bounds__(512) void k_disc_chain4(DiscArgs a) {
+__global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const float* wT, float* ops, float* part_base,
+                                                    long long* dbg, int B, int G, float inv_B, float lambda_) {
+    const Chain4Args a{params, wT, ops, part_base, dbg, B, G, inv_B, lambda_};
     constexpr int Fp = 16 * KF, Hp = 16 * KH, ldF = Fp + 4, ldH = Hp + 4;
     constexpr int ldAF = Fp + 8, ldAH = Hp + 8;   // LDS activation strides: rows 0..3 land in disjoint bank octets
     constexpr int o_b1 = Hp * ldF, o_b2 = o_b1 + Hp + Hp * ldH, o_w3 = o_b2 + Hp, o_b3 = o_w3 + Hp;
@@ -656,7 +667,7 @@ struct WgradArgs {
     double* loss_acc;
     PregatherArgs next;       // next step's inputs (next.ops == NULL on the last step)
     int nparts;               // workgroups of the chain kernel (rows of `part`)
-    int t;                    // Adam step number of this launch (1-based); its scalars sit in slot t & 1 of *st
+    int k1;                   // 1-based step index within the epoch: Adam step t = st->t0 + k1, scalars in slot t & 1
     float* wT;                // k_disc_chain4's weight images to keep in step (NULL: not maintained)
     long long* dbg;           // optional wall-clock stamps per block (test hook), NULL in production
 };
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
     // the first 2G blocks prepare the next step (two dependent global round trips: index, then row): they are
     // dispatched first so they finish with the tiles; one lane also evaluates the next step's Adam scalars
     if ((int)blockIdx.x < 2 * a.G) {
-        if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.t + 1);
+        if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
         if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
         return;
     }
@@ -701,10 +712,13 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         const int ldp = w2 ? d.ldH : d.ldF;
         // the tile's 256 parameters and moments: requested first so they arrive with the operands
         const int idx = (w2 ? d.w2 : d.w1) + (tm * 16 + ((tid & 255) >> 4)) * ldp + tn * 16 + (tid & 15);
-        float p0 = 0.f, m0 = 0.f, v0 = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
+        float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+        float4 sc = float4{0.f, 0.f, 1.f, 1.f};   // both slots of the Adam scalars; the step's parity picks one at the end
+        int t0 = 0;
         if (tid < 256 && !a.grad_out) {
             p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx];
-            step_size = a.st->step_size2[a.t & 1]; bc2_sqrt = a.st->bc2_sqrt2[a.t & 1];
+            sc = *reinterpret_cast<const float4*>(a.st->step_size2);
+            t0 = a.st->t0;
         }
         const SgStacks stk = sg_disc_stacks(const_cast<float*>(a.ops), Kt, d.Hp, d.Fp, d.ldF);
         // the two [Kt x 16] slabs this tile contracts: contiguous in the tiled stacks
@@ -745,6 +759,8 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
             for (int w = 0; w < nw; ++w) g += red[w][tid];
             if (a.grad_out) a.grad_out[idx] = g;
             else {
+                const bool odd = (t0 + a.k1) & 1;
+                const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
                 m0 = m0 + (g - m0) * (float)(1.0 - 0.9);
                 v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
                 const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
@@ -762,7 +778,9 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         // loads, 4 in flight per lane), then combine through LDS.
         const int Hp = d.Hp, nparts = a.nparts, stride = 4 * Hp, NE = 3 * Hp + 4;
         const int i = 64 * (b - (T2 + T1)) + lane;
-        const float step_size = a.st->step_size2[a.t & 1], bc2_sqrt = a.st->bc2_sqrt2[a.t & 1];
+        const float4 sc = *reinterpret_cast<const float4*>(a.st->step_size2);
+        const bool odd = (a.st->t0 + a.k1) & 1;
+        const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
         float g = 0.f;
         if (i < NE) {
             for (int s0 = wave; s0 < nparts; s0 += 16 * nw) {   // 16 loads in flight per lane: one round trip at batch 128
@@ -804,12 +822,16 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
     }
 }
 
+// End of an epoch: the steps just taken become part of the base count.
+__global__ void k_opt_commit(SgOptState* st, int n_steps) { st->t0 += n_steps; }
+
 // Data-parallel mode only: Adam from the all-reduced flat gradient (+ loss sums in its tail).
 __global__ __launch_bounds__(256) void k_disc_adam_flat(float* params, float* m, float* v, const float* grad, int total,
                                                         const SgOptState* st, float eps, float inv_B, float lambda_,
-                                                        double* loss_acc, SgDiscDesc d, float* wT, int t) {
+                                                        double* loss_acc, SgDiscDesc d, float* wT, int k1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
+        const int t = st->t0 + k1;
         sg_adam_apply(params + i, m + i, v + i, grad[i], st->step_size2[t & 1], st->bc2_sqrt2[t & 1], eps);
         if (wT) {
             if (i < d.b1) { const int r = i / d.ldF, c = i % d.ldF; if (c < d.Fp) sg_disc_img_store(d, wT, false, r, c, params[i]); }

@@ -235,12 +235,18 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         SG_CHECK(hipMalloc((void**)&a->d_stacks, sizeof(float) * (epoch_f + stack_f)));
         a->slabs_cap = slab_f;
         a->stacks_cap = epoch_f + stack_f;
+        a->scratch_key = 0;
     }
-    // ld-padding columns of the slabs are never written by the kernels and must read as zero; the
-    // epoch copy's slack rows must be finite
-    SG_CHECK(hipMemsetAsync(a->d_slabs, 0, sizeof(float) * slab_f, ctx->stream));
-    SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
-    SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 3, ctx->stream));
+    // ld-padding columns of the slabs are never written by the kernels and must read as zero; the epoch copy's
+    // slack rows must be finite.  Both hold for as long as the scratch layout is unchanged, so the 35 MB are
+    // cleared when the layout changes, not on every update.
+    const uint64_t key = ((uint64_t)G << 40) ^ ((uint64_t)slab_stride << 20) ^ ((uint64_t)mbp << 8) ^ (uint64_t)TNp ^ ((uint64_t)MT << 60);
+    if (a->scratch_key != key) {
+        SG_CHECK(hipMemsetAsync(a->d_slabs, 0, sizeof(float) * slab_f, ctx->stream));
+        SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
+        a->scratch_key = key;
+    }
+    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, ctx->stream, a->d_loss_acc, 3);
 
     float* epX = a->d_stacks;
     float* epACT = epX + (size_t)TNp * d.ldO;
@@ -293,8 +299,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     }
     SG_CHECK(hipGetLastError());
     double acc[3];
-    SG_CHECK(hipMemcpyAsync(acc, a->d_loss_acc, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
-    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
     const double nu = (double)E * M;
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
     return 0;

@@ -103,15 +103,32 @@ extern "C" int sg_rollout_download_step(sg_rollout* r, int field, int t, float* 
     return 0;
 }
 
+// slot T -> slot 0 of obs, obs_feat, masks, bad_masks in one launch (four small device-to-device copies
+// through the runtime's copy path cost more than the copy and occasionally stall for milliseconds)
+struct AfterUpdateArgs {
+    float* base[4];
+    int64_t per[4];   // floats per time slot
+    int T;
+};
+__global__ __launch_bounds__(256) void k_after_update(AfterUpdateArgs a) {
+    const int f = blockIdx.y;
+    float* p = a.base[f];
+    const int64_t per = a.per[f];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = p[(int64_t)a.T * per + i];
+}
+
 extern "C" int sg_rollout_after_update(sg_rollout* r) {
     SG_REQUIRE(r, "sg_rollout_after_update: NULL argument");
     const int fields[4] = {SG_F_OBS, SG_F_OBS_FEAT, SG_F_MASKS, SG_F_BAD_MASKS};
-    for (int f : fields) {
-        const size_t per = (size_t)r->N * r->field_width[f];
-        if (per == 0) continue;
-        SG_CHECK(hipMemcpyAsync(r->d_field[f], r->d_field[f] + (size_t)r->T * per, sizeof(float) * per,
-                                hipMemcpyDeviceToDevice, r->ctx->stream));
+    AfterUpdateArgs a;
+    a.T = r->T;
+    for (int i = 0; i < 4; ++i) {
+        a.base[i] = r->d_field[fields[i]];
+        a.per[i] = (int64_t)r->N * r->field_width[fields[i]];
     }
+    hipLaunchKernelGGL(k_after_update, dim3(32, 4), dim3(256), 0, r->ctx->stream, a);
+    SG_CHECK(hipGetLastError());
     return 0;
 }
 
@@ -201,8 +218,7 @@ extern "C" int sg_rollout_count_dones(sg_rollout* r, double* dones) {
                        (int64_t)(r->T + 1) * r->N, d_out);
     SG_CHECK(hipGetLastError());
     if (r->ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(r->ctx, d_out, 1));
-    SG_CHECK(hipMemcpyAsync(dones, d_out, sizeof(double), hipMemcpyDeviceToHost, r->ctx->stream));
-    SG_CHECK(hipStreamSynchronize(r->ctx->stream));
+    SG_TRY(sg_ctx_fetch_f64(r->ctx, d_out, dones, 1));
     return 0;
 }
 

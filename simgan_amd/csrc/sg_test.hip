@@ -201,3 +201,71 @@ extern "C" int sg_test_gemm_bench(sg_ctx* ctx, int mode, int MT, int K, int Np, 
     (void)hipFree(d_out); (void)hipFree(d_sink);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Producer/consumer flag latency inside one launch (tools/flag_probe.py): np producer blocks write `words`
+// floats each, release-fence and bump a device-scope counter; nc consumer blocks spin on it, acquire, then
+// read everything back.  Wall clock (100 MHz) stamps: producer [before fence, after atomic], consumer
+// [saw the counter, finished reading].  Spins are bounded so a logic error cannot hang the GPU.
+__global__ __launch_bounds__(512) void k_flag_probe(float* data, int words, int np, int nc, unsigned* counter, long long* stamps,
+                                                    float* sums) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b < np) {
+        for (int i = tid; i < words; i += blockDim.x) data[(size_t)b * words + i] = (float)(b + 1);
+        __syncthreads();
+        if (tid == 0) {
+            stamps[2 * b] = wall_clock64();
+            __threadfence();
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            stamps[2 * b + 1] = wall_clock64();
+        }
+    } else {
+        __shared__ int ok;
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)np && spins < (1 << 20)) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+            }
+            ok = spins < (1 << 20);
+            stamps[2 * b] = wall_clock64();
+        }
+        __syncthreads();
+        float s = 0.f;
+        if (ok)
+            for (int i = tid; i < np * words; i += blockDim.x) s += data[i];
+        s = sg_wave_sum(s);
+        __shared__ float red[8];
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+            sums[b - np] = ok ? t : -1.f;
+            stamps[2 * b + 1] = wall_clock64();
+        }
+    }
+}
+
+extern "C" int sg_test_flag_probe(sg_ctx* ctx, int np, int nc, int words, long long* stamps, float* sums) {
+    SG_REQUIRE(ctx && stamps && sums && np > 0 && nc > 0 && np + nc <= 256 && words > 0, "sg_test_flag_probe: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    float *d_data, *d_sums;
+    unsigned* d_cnt;
+    long long* d_st;
+    SG_CHECK(hipMalloc((void**)&d_data, sizeof(float) * (size_t)np * words));
+    SG_CHECK(hipMalloc((void**)&d_sums, sizeof(float) * nc));
+    SG_CHECK(hipMalloc((void**)&d_cnt, 64));
+    SG_CHECK(hipMalloc((void**)&d_st, sizeof(long long) * 2 * (np + nc)));
+    for (int rep = 0; rep < 3; ++rep) {   // last repetition is the one reported (warm code, warm TLB)
+        SG_CHECK(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+        SG_CHECK(hipMemsetAsync(d_data, 0, sizeof(float) * (size_t)np * words, ctx->stream));
+        hipLaunchKernelGGL(k_flag_probe, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+    }
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_CHECK(hipMemcpy(stamps, d_st, sizeof(long long) * 2 * (np + nc), hipMemcpyDeviceToHost));
+    SG_CHECK(hipMemcpy(sums, d_sums, sizeof(float) * nc, hipMemcpyDeviceToHost));
+    (void)hipFree(d_data); (void)hipFree(d_sums); (void)hipFree(d_cnt); (void)hipFree(d_st);
+    return 0;
+}

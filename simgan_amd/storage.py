@@ -126,11 +126,12 @@ class RolloutStorage(object):
 
     def after_update(self):
         """a2c/storage.py:96-101"""
+        if self.device_resident:   # the device copy is the rollout; the host mirrors are refreshed by sync_from_device()
+            _lib.check(self.lib.sg_rollout_after_update(self.h))
+            return
         for name in ("obs", "obs_feat", "recurrent_hidden_states", "masks", "bad_masks"):
             t = getattr(self, name)
             t[0] = t[-1]
-        if self.device_resident:
-            _lib.check(self.lib.sg_rollout_after_update(self.h))
 
     def compute_returns(self, next_value, use_gae, gamma, gae_lambda, use_proper_time_limits=True):
         """a2c/storage.py:103-142, on device (one thread per env column, reverse scan over T)."""
