@@ -149,8 +149,8 @@ def cpu_baseline(w, expert, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,11 +215,11 @@ def main():
                                    f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}",
                        "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_disc_chain", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": "k_disc_chain4", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
                          "traffic": None, "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
                          "algorithmic_flops_per_launch": work["d_chain_flops"],
-                         "note": "serial chain of 16 workgroups per 128-row step: latency-bound, see DESIGN.md section 4",
+                         "note": "serial chain of 7 dependent GEMM phases on 96 four-row workgroups per 128-row step: latency-bound, see DESIGN.md section 4",
                          "whole_update": {"TFLOP/s": round(work["flops"] * args.steps / elapsed / 1e12, 3),
                                           "GB/s": round(work["bytes"] * args.steps / elapsed / 1e9, 2),
                                           "frac_mfma": round(work["flops"] * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),

@@ -151,6 +151,8 @@ struct sg_rollout {
 
 struct sg_ppo {
     uint64_t scratch_key = 0;    // layout the scratch buffers were last cleared for
+    hipGraphExec_t steps_graph = nullptr;   // the update's optimizer steps, captured once and replayed
+    uint64_t steps_graph_key[16] = {0};
     sg_ctx* ctx;
     sg_policy* policy;
     sg_ppo_config cfg;

@@ -123,6 +123,7 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     if (a->d_perms) (void)hipFree(a->d_perms);
     if (a->d_loss_acc) (void)hipFree(a->d_loss_acc);
     if (a->d_dbg) (void)hipFree(a->d_dbg);
+    if (a->steps_graph) (void)hipGraphExecDestroy(a->steps_graph);
     delete a;
     return 0;
 }
@@ -276,26 +277,61 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     const int nblk = (d.total + 8 + 255) / 256;
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
 
-    for (int e = 0; e < E; ++e) {
-        ga.perm = a->d_perms + (size_t)e * TN;
-        hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
-        for (int k = 0; k < M; ++k) {
-            const size_t rb = (size_t)k * mb;
-            pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
-            pa.wbuf_floats = wb_f;
-            launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
-            pa.wbuf_floats = wb_b;
-            launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa);
-            SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
-                      d.total, a->d_grad, a->d_part, st);
-            if (ctx->use_comm) {
-                SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
-                hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
+    // The E*M optimizer steps (+ one row gather per epoch) depend only on buffer addresses, the minibatch geometry
+    // and the PPO coefficients: the learning rate and Adam's step count live on the device.  The sequence is
+    // captured into a hipGraph once and replayed per update, so the host issues one call instead of ~650.
+    auto enqueue_steps = [&]() -> int {
+        for (int e = 0; e < E; ++e) {
+            ga.perm = a->d_perms + (size_t)e * TN;
+            hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
+            for (int k = 0; k < M; ++k) {
+                const size_t rb = (size_t)k * mb;
+                pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
+                pa.wbuf_floats = wb_f;
+                launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
+                pa.wbuf_floats = wb_b;
+                launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa);
+                SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
+                          d.total, a->d_grad, a->d_part, st);
+                if (ctx->use_comm) {
+                    SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
+                    hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
+                }
+                SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
+                          a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
+                          a->d_loss_acc);
             }
-            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
-                      a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
-                      a->d_loss_acc);
         }
+        return 0;
+    };
+    const char* genv = getenv("SG_PPO_GRAPH");
+    const bool use_graph = !ctx->use_comm && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
+    if (!use_graph) {
+        SG_TRY(enqueue_steps());
+    } else {
+        uint32_t fbits[6];
+        const float fv[6] = {a->cfg.clip_param, a->cfg.value_loss_coef, a->cfg.entropy_coef, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B};
+        memcpy(fbits, fv, sizeof fbits);
+        const uint64_t key[16] = {(uint64_t)(uintptr_t)a->d_slabs, (uint64_t)(uintptr_t)a->d_stacks, (uint64_t)(uintptr_t)a->d_perms,
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_OBS], (uint64_t)(uintptr_t)r->d_field[SG_F_ACTIONS],
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_RETURNS], (uint64_t)(uintptr_t)a->policy->d_params,
+                                  (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
+                                  ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
+                                  ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full};
+        if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
+            if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
+            hipGraph_t graph = nullptr;
+            SG_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_steps();
+            const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+            SG_REQUIRE(rc == 0, "sg_ppo_update: launch failed during graph capture");
+            SG_CHECK(ce);
+            SG_CHECK(hipGraphInstantiate(&a->steps_graph, graph, nullptr, nullptr, 0));
+            SG_CHECK(hipGraphDestroy(graph));
+            memcpy(a->steps_graph_key, key, sizeof key);
+        }
+        SG_CHECK(hipGraphLaunch(a->steps_graph, ctx->stream));
     }
     SG_CHECK(hipGetLastError());
     double acc[3];
