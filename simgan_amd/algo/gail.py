@@ -84,6 +84,11 @@ class Discriminator(object):
         _lib.check(self.lib.sg_disc_get_adam(self.h, _lib.fptr(m), _lib.fptr(v), n, C.byref(step)))
         return m, v, step.value
 
+    def set_adam(self, m, v, step):
+        """Restore the optimizer state (torch.optim.Adam exp_avg / exp_avg_sq / step, a2c/algo/gail.py:48)."""
+        m, v = _lib.as_f32(m).reshape(-1), _lib.as_f32(v).reshape(-1)
+        _lib.check(self.lib.sg_disc_set_adam(self.h, _lib.fptr(m), _lib.fptr(v), m.size, int(step)))
+
     def train(self, mode=True):
         return self
 

@@ -124,9 +124,7 @@ def fill_rollout(ro, g):
             getattr(ro, name).copy_(getattr(ro, name).new_tensor(g[name]))
 
 
-@pytest.mark.parametrize("name", PPO_CASES)
-def test_ppo_update_golden(sg, name):
-    g = load(name)
+def _ppo_problem(sg, g):
     m = g["meta"]
     p = make_policy(sg, m)
     p.set_flat_params(g["params0"])
@@ -134,6 +132,14 @@ def test_ppo_update_golden(sg, name):
     fill_rollout(ro, g)
     agent = sg.algo.PPO(p, m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], m["value_loss_coef"],
                         m["entropy_coef"], lr=m["lr"], eps=m["eps"], max_grad_norm=m["max_grad_norm"])
+    return p, agent, ro
+
+
+@pytest.mark.parametrize("name", PPO_CASES)
+def test_ppo_update_golden(sg, name):
+    g = load(name)
+    m = g["meta"]
+    p, agent, ro = _ppo_problem(sg, g)
     losses = agent.update(ro, perms=g["perms"])
     assert_close(ro.device_advantages(), g["advantages"], rtol=1e-5, what="advantages")
     assert_close(losses, g["losses"], what="ppo losses")
@@ -142,6 +148,23 @@ def test_ppo_update_golden(sg, name):
     assert_close(mm, g["adam_m"], rtol=1e-3, atol=1e-7, what="adam m")
     assert_close(vv, g["adam_v"], rtol=1e-3, atol=1e-10, what="adam v")
     assert_close(p.get_flat_params(), g["params1"], what="params after update")
+
+
+def test_ppo_graph_replay_is_bit_exact(sg, monkeypatch):
+    """Two updates through the captured hipGraph equal two updates launched kernel by kernel."""
+    g = load("ppo_mlp_northstar")
+    m = g["meta"]
+
+    def run():
+        pol, agent, ro = _ppo_problem(sg, g)
+        out = [agent.update(ro, perms=g["perms"]) for _ in range(2)]
+        return out, pol.get_flat_params(), agent.get_adam()
+
+    a = run()
+    monkeypatch.setenv("SG_PPO_GRAPH", "0")
+    b = run()
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1]) and a[2][2] == b[2][2] == 2 * m["ppo_epoch"] * m["num_mini_batch"]
 
 
 def test_ppo_lr_schedule_and_errors(sg):
@@ -227,6 +250,41 @@ def test_disc_update_classic_golden(sg, name):
     assert D.last_n_steps == int(g["n_steps"])
     assert_close(losses, g["losses"], what="classic D losses")
     assert_close(D.get_flat_params(), g["params_after"], what="classic D params")
+
+
+@pytest.mark.parametrize("name", ["disc_tiny", "disc_northstar"])
+def test_disc_resume_and_graph_replay_are_bit_exact(sg, name, monkeypatch):
+    """Checkpoint / resume (weights + Adam moments + step count into a fresh object) continues the trajectory
+    bit for bit, and the hipGraph replay of an epoch equals launching the same kernels one by one."""
+    g = load(name)
+    m = g["meta"]
+    ro = sg.RolloutStorage(m["T"], m["N"], (3,), Box((2,)), 1, m["F"])
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(g["obs_feat"]))
+    loader = Loader(g["expert"], m["B"])
+    kw0 = dict(expert_perm=g["expert_perm0"], policy_perm=g["policy_perm0"], alpha=g["alpha0"])
+    kw1 = dict(expert_perm=g["expert_perm1"], policy_perm=g["policy_perm1"], alpha=g["alpha1"])
+
+    def fresh():
+        D = sg.algo.gail.Discriminator(m["F"], m["Hd"], None)
+        D.set_flat_params(g["params0"])
+        return D
+
+    A = fresh()
+    A.update_gail_dyn(loader, ro, **kw0)
+    mm, vv, step = A.get_adam()
+    assert step == int(g["n_steps0"])
+    Bd = fresh()
+    Bd.set_flat_params(A.get_flat_params())
+    Bd.set_adam(mm, vv, step)
+    la = A.update_gail_dyn(loader, ro, **kw1)       # second epoch: graph replay on A
+    lb = Bd.update_gail_dyn(loader, ro, **kw1)      # first epoch of a resumed object
+    assert la == lb and np.array_equal(A.get_flat_params(), Bd.get_flat_params())
+    assert_close(A.get_flat_params(), g["params_after1"], what="resumed trajectory vs reference")
+    monkeypatch.setenv("SG_DISC_GRAPH", "0")
+    Cd = fresh()
+    Cd.update_gail_dyn(loader, ro, **kw0)
+    lc = Cd.update_gail_dyn(loader, ro, **kw1)
+    assert lc == la and np.array_equal(Cd.get_flat_params(), A.get_flat_params())
 
 
 def test_disc_short_expert_is_an_error(sg):
