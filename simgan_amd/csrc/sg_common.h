@@ -150,6 +150,7 @@ struct sg_rollout {
 };
 
 struct sg_ppo {
+    int64_t opt_t = 0;           // completed Adam steps (mirrors SgOptState::t0 on the device)
     uint64_t scratch_key = 0;    // layout the scratch buffers were last cleared for
     hipGraphExec_t steps_graph = nullptr;   // the update's optimizer steps, captured once and replayed
     uint64_t steps_graph_key[16] = {0};
@@ -227,6 +228,8 @@ __device__ __forceinline__ void sg_opt_advance(SgOptState* st) {
     st->step_size = (float)((double)st->lr / bc1);
     st->bc2_sqrt = (float)sqrt(bc2);
 }
+// End of an epoch / update: the steps just taken become part of the base count.
+__attribute__((unused)) static __global__ void k_opt_commit(SgOptState* st, int n_steps) { st->t0 += n_steps; }
 // bias-correction scalars of Adam step t (1-based) into slot t & 1
 __device__ __forceinline__ void sg_opt_prepare(SgOptState* st, int t) {
     const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);

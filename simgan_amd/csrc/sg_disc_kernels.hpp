@@ -822,9 +822,6 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
     }
 }
 
-// End of an epoch: the steps just taken become part of the base count.
-__global__ void k_opt_commit(SgOptState* st, int n_steps) { st->t0 += n_steps; }
-
 // Data-parallel mode only: Adam from the all-reduced flat gradient (+ loss sums in its tail).
 __global__ __launch_bounds__(256) void k_disc_adam_flat(float* params, float* m, float* v, const float* grad, int total,
                                                         const SgOptState* st, float eps, float inv_B, float lambda_,

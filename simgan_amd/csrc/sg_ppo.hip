@@ -102,7 +102,7 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
     SG_CHECK(hipMalloc((void**)&a->d_grad, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&a->d_state, sizeof(SgOptState)));
     SG_CHECK(hipMalloc((void**)&a->d_loss_acc, sizeof(double) * 8));
-    SG_CHECK(hipMalloc((void**)&a->d_part, sizeof(float) * ((tot + 255) / 256 + 8)));
+    SG_CHECK(hipMalloc((void**)&a->d_part, sizeof(float) * ((tot + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS + 8)));
     SG_CHECK(hipMemsetAsync(a->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_v, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 8, ctx->stream));
@@ -142,14 +142,12 @@ extern "C" int sg_ppo_get_adam(sg_ppo* a, float* m, float* v, int64_t n, int64_t
     const SgPolicyDesc& d = a->policy->desc;
     SG_REQUIRE(n == sg_policy_flat_count(d), "sg_ppo_get_adam: bad length");
     std::vector<float> pm(d.total), pv(d.total);
-    SgOptState st;
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
     SG_CHECK(hipMemcpy(pm.data(), a->d_m, sizeof(float) * d.total, hipMemcpyDeviceToHost));
     SG_CHECK(hipMemcpy(pv.data(), a->d_v, sizeof(float) * d.total, hipMemcpyDeviceToHost));
-    SG_CHECK(hipMemcpy(&st, a->d_state, sizeof st, hipMemcpyDeviceToHost));
     sg_policy_unpad(d, pm.data(), m);
     sg_policy_unpad(d, pv.data(), v);
-    *step = (int64_t)st.step;
+    *step = a->opt_t;
     return 0;
 }
 
@@ -160,11 +158,13 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     std::vector<float> pm(d.total, 0.f), pv(d.total, 0.f);
     sg_policy_pad(d, m, pm.data());
     sg_policy_pad(d, v, pv.data());
-    const float fs = (float)step;
+    SG_REQUIRE(step >= 0 && step < (1ll << 30), "sg_ppo_set_adam: step out of range");
+    const int t0 = (int)step;
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
     SG_CHECK(hipMemcpy(a->d_m, pm.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
     SG_CHECK(hipMemcpy(a->d_v, pv.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
-    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(a->d_state)->step, &fs, sizeof(float), hipMemcpyHostToDevice));
+    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(a->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice));
+    a->opt_t = step;
     return 0;
 }
 
@@ -210,8 +210,9 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
             SG_TRY(sg_fill_perm(ctx, a->d_perms + (size_t)e * TN, TN, seed, (uint64_t)e * 2654435761ull + (uint64_t)ctx->rank));
     }
 
-    // launch geometry: 32-row tiles when that still gives >= half a workgroup per CU, else 16
-    int MT = ((mb + 31) / 32) * d.n_trunks >= ctx->num_cu / 2 ? 2 : 1;
+    // launch geometry: 16-row groups (more workgroups in flight per CU hide the phases' latencies) while the
+    // per-row-group gradient slabs the reduction has to stream stay small (<= 24 MB), else 32-row groups
+    int MT = (size_t)((mb + 15) / 16) * (size_t)(d.total + 8) * sizeof(float) > ((size_t)24 << 20) ? 2 : 1;
     if (const char* e = getenv("SG_PPO_ROWS")) {   // tuning knob
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) MT = v / 16;
@@ -266,6 +267,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     pa.clip = a->cfg.clip_param; pa.vcoef = a->cfg.value_loss_coef; pa.ecoef = a->cfg.entropy_coef;
     pa.use_clipped = a->cfg.use_clipped_value_loss;
     pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
+    pa.st = reinterpret_cast<SgOptState*>(a->d_state); pa.G = G; pa.k1 = 0;
     for (int t = 0; t < 3; ++t) {
         const bool on = t < d.n_trunks;
         pa.H1[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
@@ -275,6 +277,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     const int wb_f = max_trunk_floats(d), wb_b = max_bwd_floats(d);
     const size_t lds_f = ppo_fwd_lds(d, MT), lds_b = ppo_bwd_lds(d, MT);
     const int nblk = (d.total + 8 + 255) / 256;
+    const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
 
     // The E*M optimizer steps (+ one row gather per epoch) depend only on buffer addresses, the minibatch geometry
@@ -290,18 +293,20 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
                 pa.wbuf_floats = wb_f;
                 launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
                 pa.wbuf_floats = wb_b;
-                launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa);
-                SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk), dim3(256), 0, a->d_slabs, G, slab_stride,
-                          d.total, a->d_grad, a->d_part, st);
+                pa.k1 = e * M + k + 1;
+                launch_ppo_bwd(ctx, MT, d, dim3(G + 1, d.n_trunks), lds_b, pa);
+                SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
+                          d.total, a->d_grad, a->d_part);
                 if (ctx->use_comm) {
                     SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
                     hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
-                          a->d_grad, a->d_part, nblk, d.total, st, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
-                          a->d_loss_acc);
+                          a->d_grad, a->d_part, ctx->use_comm ? nblk : nblk_r, d.total, st, a->cfg.eps, a->cfg.max_grad_norm,
+                          pa.inv_B, a->d_loss_acc, e * M + k + 1);
             }
         }
+        hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, st, E * M);
         return 0;
     };
     const char* genv = getenv("SG_PPO_GRAPH");
@@ -338,6 +343,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
     const double nu = (double)E * M;
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
+    a->opt_t += (int64_t)E * M;
     return 0;
 }
 

@@ -11,8 +11,8 @@
 //                         action dims), back-propagate, form the row group's partial gradient of the
 //                         trunk (three TN GEMMs on the LDS tiles, bias sums from the epilogues) and
 //                         write it to the row group's slab.
-//   k_ppo_reduce          slab sum per parameter (8 loads in flight), per-block sum of squares,
-//                         advance Adam's t.
+//   k_ppo_reduce          slab sum per parameter (64 parameters per block, waves split the slabs), per-block
+//                         sum of squares.
 //   k_ppo_adam            clip coefficient max_norm/(||g||+1e-6) (<= 1), then Adam.
 // Splitting forward / backward per trunk keeps every workgroup's LDS to one trunk's parameters
 // (the split policy's trunks are 69-98 KB each) and lets all trunks of all row groups run
@@ -42,6 +42,8 @@ struct PpoArgs {
     int ldP;              // stride of the OUT stacks (max over trunks)
     int wbuf_floats;
     long long* dbg;       // optional phase timestamps [block][16] (test hook), NULL in production
+    SgOptState* st;       // k_ppo_bwd: one spare lane prepares this step's Adam scalars (step st->t0 + k1)
+    int k1, G;            // 1-based step index within the update; row groups (blockIdx.x == G is the spare block)
 };
 
 #define SG_PPO_STAMP(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[blockIdx.x * 16 + (n)] = clock64(); } while (0)
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
 template <int MT, int KO, int KH>
 __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x == a.G) {   // spare block: the double-precision pow() of Adam's bias corrections, off every
+        if (blockIdx.y == 0 && threadIdx.x == 0) sg_opt_prepare(a.st, a.st->t0 + a.k1);   // row group's critical path
+        return;
+    }
     constexpr int R = 16 * MT;
     SgPolicyDesc d = a.d;
     if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
@@ -326,31 +332,36 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     sg_grad_tn<MT>(H1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, false);
 }
 
-// grad[i] = sum over slabs; part[block] = sum of squares of this block's grads; bumps Adam's t.
+// grad[i] = sum over slabs; part[block] = sum of squares of this block's grads.  A block owns 64 consecutive
+// parameters; its 4 waves each sum a quarter of the slabs (16 independent loads in flight per lane, i.e. two
+// round trips for 128 slabs instead of sixteen) and combine through LDS in a fixed order.
+#define SG_PPO_REDUCE_PARAMS 64
 __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_slabs, int slab_stride, int total,
-                                                    float* grad, float* part, SgOptState* st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    float* grad, float* part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * SG_PPO_REDUCE_PARAMS + lane;
     float g = 0.f;
     if (i < total + 8) {
-        // 8 independent partial sums keep 8 slab loads in flight; combined in a fixed order
-        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 8 <= n_slabs; s += 8) {
+        for (int s0 = wave; s0 < n_slabs; s0 += 64) {
+            float t[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(s + u) * slab_stride + i];
+            for (int u = 0; u < 16; ++u) {
+                const int sidx = s0 + 4 * u;
+                t[u] = slabs[(size_t)(sidx < n_slabs ? sidx : s0) * slab_stride + i];   // clamped, zeroed below: no branch
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) g += (s0 + 4 * u < n_slabs) ? t[u] : 0.f;
         }
-        for (; s < n_slabs; ++s) p[0] += slabs[(size_t)s * slab_stride + i];
-        g = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        grad[i] = g;
     }
-    float sq = (i < total) ? g * g : 0.f;
-    sq = sg_wave_sum(sq);
-    __shared__ float ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sq;
+    red[wave][lane] = g;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-        if (blockIdx.x == 0) sg_opt_advance(st);
+    if (wave == 0) {
+        g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (i < total + 8) grad[i] = g;
+        float sq = (i < total) ? g * g : 0.f;
+        sq = sg_wave_sum(sq);
+        if (lane == 0) part[blockIdx.x] = sq;
     }
 }
 
@@ -369,18 +380,23 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* grad, int total, flo
 __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float* v, const float* grad,
                                                   const float* part, int n_part, int total,
                                                   const SgOptState* st, float eps, float max_norm,
-                                                  float inv_mb, double* loss_acc) {
+                                                  float inv_mb, double* loss_acc, int k1) {
     __shared__ float s_coef;
-    const float s_step_size = st->step_size, s_bc2_sqrt = st->bc2_sqrt;
-    if (threadIdx.x < 64) {
+    // Adam step t = st->t0 + k1; its bias-correction scalars were prepared in slot t & 1 by this step's k_ppo_bwd
+    const int t = st->t0 + k1;
+    const float s_step_size = st->step_size2[t & 1], s_bc2_sqrt = st->bc2_sqrt2[t & 1];
+    __shared__ float s_ws[4];
+    {   // ||g||^2 from the per-block partial sums: all 256 threads load (a few independent loads each)
         float s = 0.f;
-        for (int j = threadIdx.x; j < n_part; j += 64) s += part[j];
+        for (int j = threadIdx.x; j < n_part; j += 256) s += part[j];
         s = sg_wave_sum(s);
-        if (threadIdx.x == 0) {
-            const float norm = sqrtf(s);
-            float coef = max_norm / (norm + 1e-6f);
-            s_coef = coef > 1.f ? 1.f : coef;
-        }
+        if ((threadIdx.x & 63) == 0) s_ws[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((s_ws[0] + s_ws[1]) + (s_ws[2] + s_ws[3]));
+        float coef = max_norm / (norm + 1e-6f);
+        s_coef = coef > 1.f ? 1.f : coef;
     }
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
