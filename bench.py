@@ -206,6 +206,12 @@ def main():
         dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
         achieved = work["d_chain_flops"] / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
         name, num_cu, hbm = ctx.device_info()
+        traffic = None   # PMC passes cannot run inside the timed process: the committed summary of the last profile run
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["k_disc_chain4"]["hbm_bytes_per_launch"] if args.workload == "northstar" else None
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "env-steps/sec of GAIL-dyn PPO update", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -217,7 +223,7 @@ def main():
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_disc_chain4", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
-                         "traffic": None, "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)", "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
                          "algorithmic_flops_per_launch": work["d_chain_flops"],
                          "note": "serial chain of 7 dependent GEMM phases on 96 four-row workgroups per 128-row step: latency-bound, see DESIGN.md section 4",
                          "whole_update": {"TFLOP/s": round(work["flops"] * args.steps / elapsed / 1e12, 3),
