@@ -207,25 +207,57 @@ extern "C" int sg_test_gemm_bench(sg_ctx* ctx, int mode, int MT, int K, int Np, 
 // floats each, release-fence and bump a device-scope counter; nc consumer blocks spin on it, acquire, then
 // read everything back.  Wall clock (100 MHz) stamps: producer [before fence, after atomic], consumer
 // [saw the counter, finished reading].  Spins are bounded so a logic error cannot hang the GPU.
+template <int MODE>   // 0: plain stores + __threadfence (L2 write-back); 1: agent-scope (write-through) stores + one counter;
+                      // 2: write-through stores + one flag word per producer, consumers poll all flags with coalesced loads
 __global__ __launch_bounds__(512) void k_flag_probe(float* data, int words, int np, int nc, unsigned* counter, long long* stamps,
                                                     float* sums) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b < np) {
-        for (int i = tid; i < words; i += blockDim.x) data[(size_t)b * words + i] = (float)(b + 1);
-        __syncthreads();
+        for (int i = tid; i < words; i += blockDim.x) {
+            if (MODE == 0) data[(size_t)b * words + i] = (float)(b + 1);
+            else __hip_atomic_store(data + (size_t)b * words + i, (float)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();   // s_waitcnt vmcnt(0) + barrier: every store of the block has been acknowledged
         if (tid == 0) {
             stamps[2 * b] = wall_clock64();
-            __threadfence();
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (MODE == 0) {
+                __threadfence();
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (MODE == 1) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(counter + 16 + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             stamps[2 * b + 1] = wall_clock64();
         }
     } else {
         __shared__ int ok;
-        if (tid == 0) {
+        if (MODE == 2) {
+            if (tid < 64) {   // one wave polls every producer's flag: ceil(np/64) coalesced loads per round
+                int spins = 0;
+                bool all = false;
+                while (!all && spins < (1 << 20)) {
+                    bool mine = true;
+                    for (int j = tid; j < np; j += 64)
+                        mine = mine && __hip_atomic_load(counter + 16 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    all = __all(mine);
+                    if (!all) __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                }
+                if (tid == 0) { ok = spins < (1 << 20); stamps[2 * b] = wall_clock64(); }
+            }
+        } else if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)np && spins < (1 << 20)) {
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
+            if (MODE == 0) {
+                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)np && spins < (1 << 20)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                }
+            } else {
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)np && spins < (1 << 20)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                }
             }
             ok = spins < (1 << 20);
             stamps[2 * b] = wall_clock64();
@@ -233,7 +265,8 @@ __global__ __launch_bounds__(512) void k_flag_probe(float* data, int words, int 
         __syncthreads();
         float s = 0.f;
         if (ok)
-            for (int i = tid; i < np * words; i += blockDim.x) s += data[i];
+            for (int i = tid; i < np * words; i += blockDim.x)
+                s += MODE == 0 ? data[i] : __hip_atomic_load(data + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s = sg_wave_sum(s);
         __shared__ float red[8];
         if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -247,7 +280,7 @@ __global__ __launch_bounds__(512) void k_flag_probe(float* data, int words, int 
     }
 }
 
-extern "C" int sg_test_flag_probe(sg_ctx* ctx, int np, int nc, int words, long long* stamps, float* sums) {
+extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int words, long long* stamps, float* sums) {
     SG_REQUIRE(ctx && stamps && sums && np > 0 && nc > 0 && np + nc <= 256 && words > 0, "sg_test_flag_probe: bad argument");
     SG_CHECK(hipSetDevice(ctx->device));
     float *d_data, *d_sums;
@@ -255,12 +288,14 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int np, int nc, int words, long l
     long long* d_st;
     SG_CHECK(hipMalloc((void**)&d_data, sizeof(float) * (size_t)np * words));
     SG_CHECK(hipMalloc((void**)&d_sums, sizeof(float) * nc));
-    SG_CHECK(hipMalloc((void**)&d_cnt, 64));
+    SG_CHECK(hipMalloc((void**)&d_cnt, 4096));
     SG_CHECK(hipMalloc((void**)&d_st, sizeof(long long) * 2 * (np + nc)));
     for (int rep = 0; rep < 3; ++rep) {   // last repetition is the one reported (warm code, warm TLB)
-        SG_CHECK(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+        SG_CHECK(hipMemsetAsync(d_cnt, 0, 4096, ctx->stream));
         SG_CHECK(hipMemsetAsync(d_data, 0, sizeof(float) * (size_t)np * words, ctx->stream));
-        hipLaunchKernelGGL(k_flag_probe, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+        if (mode == 0) hipLaunchKernelGGL(k_flag_probe<0>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+        else if (mode == 1) hipLaunchKernelGGL(k_flag_probe<1>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+        else hipLaunchKernelGGL(k_flag_probe<2>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
     }
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipStreamSynchronize(ctx->stream));
