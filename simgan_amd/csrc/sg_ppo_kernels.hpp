@@ -19,6 +19,7 @@
 // concurrently: 2 x 128 workgroups for Policy, 3 x 128 for SplitPolicy at 4096-row minibatches.
 #pragma once
 #include "sg_common.h"
+#include "sg_thin.hpp"
 
 #define HALF_LOG_2PI 0.91893853320467274178f
 
@@ -177,36 +178,53 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     const int row0 = blockIdx.x * R;
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 
+    SG_PPO_STAMP(8);
+    // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
     sg_stage_issue<12>(wv, a.params + tr.off + tr.w2, wfl / 4);
-    {   // this row group's inputs, activations and head outputs (contiguous rows)
-        const float4* gx = reinterpret_cast<const float4*>(a.X + (size_t)row0 * ldO);
-        float4* lx = reinterpret_cast<float4*>(X);
-        for (int i = tid; i < R * ldO / 4; i += blockDim.x) lx[i] = gx[i];
-        const float4* g1 = reinterpret_cast<const float4*>(a.H1[t] + (size_t)row0 * ldH);
-        const float4* g2 = reinterpret_cast<const float4*>(a.H2[t] + (size_t)row0 * ldH);
-        float4* l1 = reinterpret_cast<float4*>(H1);
-        float4* l2 = reinterpret_cast<float4*>(H2);
-        for (int i = tid; i < R * ldH / 4; i += blockDim.x) { l1[i] = g1[i]; l2[i] = g2[i]; }
-        const int ta = critic ? t : 0;
-        const float4* go0 = reinterpret_cast<const float4*>(a.OUT[ta] + (size_t)row0 * ldP);
-        float4* lo0 = reinterpret_cast<float4*>(O0);
-        for (int i = tid; i < R * ldP / 4; i += blockDim.x) lo0[i] = go0[i];
-        if (!critic && !mlp) {
-            const float4* go1 = reinterpret_cast<const float4*>(a.OUT[1] + (size_t)row0 * ldP);
-            float4* lo1 = reinterpret_cast<float4*>(O1);
-            for (int i = tid; i < R * ldP / 4; i += blockDim.x) lo1[i] = go1[i];
-        }
-        if (!critic)
-            for (int i = tid; i < R * A; i += blockDim.x) ACT[i] = a.ACT[(size_t)row0 * A + i];
-        if (tid < R) {
-            VALID[tid] = row0 + tid < a.mb;
+    constexpr int UX = MT <= 2 ? 4 : 8;          // float4 per thread for an [R][ld <= 116] tile at 256 threads
+    constexpr int UO = MT <= 2 ? 2 : 4;          // ... for an [R][ldP <= 64] tile
+    const int ta = critic ? t : 0;
+    const bool two_heads = !critic && !mlp;
+    const float* gX = a.X + (size_t)row0 * ldO;
+    const float* gH1 = a.H1[t] + (size_t)row0 * ldH;
+    const float* gH2 = a.H2[t] + (size_t)row0 * ldH;
+    const float* gO0 = a.OUT[ta] + (size_t)row0 * ldP;
+    const float* gO1 = a.OUT[two_heads ? 1 : ta] + (size_t)row0 * ldP;
+    float4 xv[UX], h1v[UX], h2v[UX], o0v[UO], o1v[UO];
+    sg_stage_issue<UX>(xv, gX, R * ldO / 4);
+    sg_stage_issue<UX>(h1v, gH1, R * ldH / 4);
+    sg_stage_issue<UX>(h2v, gH2, R * ldH / 4);
+    sg_stage_issue<UO>(o0v, gO0, R * ldP / 4);
+    if (two_heads) sg_stage_issue<UO>(o1v, gO1, R * ldP / 4);
+    float actv[2] = {0.f, 0.f}, scv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!critic) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) SC[q * R + tid] = a.SC[(size_t)q * a.sc_stride + row0 + tid];
-        }
+        for (int u = 0; u < 2; ++u) { const int i = tid + u * 256; actv[u] = a.ACT[(size_t)row0 * A + (i < R * A ? i : 0)]; }
+    }
+    {
+        const int r = tid < R ? tid : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scv[q] = a.SC[(size_t)q * a.sc_stride + row0 + r];
+    }
+    sg_stage_commit<UX>(X, xv, gX, R * ldO / 4);
+    sg_stage_commit<UX>(H1, h1v, gH1, R * ldH / 4);
+    sg_stage_commit<UX>(H2, h2v, gH2, R * ldH / 4);
+    sg_stage_commit<UO>(O0, o0v, gO0, R * ldP / 4);
+    if (two_heads) sg_stage_commit<UO>(O1, o1v, gO1, R * ldP / 4);
+    if (!critic) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + u * 256; if (i < R * A) ACT[i] = actv[u]; }
+        for (int i = tid + 512; i < R * A; i += blockDim.x) ACT[i] = a.ACT[(size_t)row0 * A + i];
+    }
+    if (tid < R) {
+        VALID[tid] = row0 + tid < a.mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
     sg_stage_commit<12>(Wimg, wv, a.params + tr.off + tr.w2, wfl / 4);
     __syncthreads();
+    SG_PPO_STAMP(9);
 
     // ---- loss and d(loss)/d(head outputs)  (a2c/algo/ppo.py:92-106)
     if (critic) {
@@ -241,8 +259,49 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
         for (int r = tid >> 5; r < R; r += rows_per_pass) {
             float* o0 = O0 + r * ldP;
             float* o1 = O1 + r * ldP;
+            if (A <= 32) {
+                // one action dimension per lane (every shipped policy): sigma, diff are computed once and kept
+                const int k = tid & 31;
+                float mean = 0.f, ls = 0.f, sigma = 1.f, diff = 0.f, lp = 0.f, en = 0.f;
+                float *pm = nullptr, *pl = nullptr;
+                if (k < A) {
+                    if (mlp) { pm = o0 + k; pl = o1 + k; mean = *pm; ls = W[tra.ex + k]; }
+                    else if (k < d.nc) { pm = o0 + k; pl = o0 + d.nc + k; mean = *pm; ls = *pl; }
+                    else { pm = o1 + (k - d.nc); pl = o1 + (d.na + k - d.nc); mean = *pm; ls = *pl; }
+                    sigma = expf(ls);
+                    diff = ACT[r * A + k] - mean;
+                    const float lsig = logf(sigma);
+                    lp = -(diff * diff) / (2.f * sigma * sigma) - lsig - HALF_LOG_2PI;
+                    en = 0.5f + HALF_LOG_2PI + lsig;
+                }
+                // 32 lanes = two 16-lane DPP rows: row sums on the VALU, then one cross-row exchange
+                lp = sg4_rowsum16(lp); en = sg4_rowsum16(en);
+                const float logp = lp + __shfl_xor(lp, 16), ent = en + __shfl_xor(en, 16);
+                const bool valid = VALID[r];
+                float dlogp = 0.f, la = 0.f;
+                if (valid) {
+                    const float adv = SC[1 * R + r];
+                    const float ratio = expf(logp - SC[0 * R + r]);
+                    const float surr1 = ratio * adv;
+                    const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
+                    const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);  // torch.min tie -> 1/2, 1/2
+                    const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
+                    dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
+                    la = -fminf(surr1, surr2);
+                }
+                const float dent = valid ? a.ecoef * a.inv_B : 0.f;
+                if (k < A) {
+                    const float var = sigma * sigma;
+                    *pm = dlogp * diff / var;
+                    *pl = dlogp * (diff * diff / var - 1.f) - dent;
+                } else if (mlp && k < tra.Pp) {
+                    o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
+                }
+                if (k == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
+                continue;
+            }
             float logp = 0.f, ent = 0.f;
-            for (int k0 = 0; k0 < A; k0 += 32) {       // A <= 32 for every shipped policy: one trip
+            for (int k0 = 0; k0 < A; k0 += 32) {
                 const int k = k0 + (tid & 31);
                 float lp = 0.f, en = 0.f;
                 if (k < A) {
@@ -283,21 +342,24 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
                     *pm = dlogp * diff / var;
                     *pl = dlogp * (diff * diff / var - 1.f) - dent;
                 } else if (mlp && k < tra.Pp) {
-                    o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
+                    o1[k] = 0.f;
                 }
             }
             if ((tid & 31) == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
         }
     }
     __syncthreads();
+    SG_PPO_STAMP(10);
     float* dout = (critic || t == 0) ? O0 : O1;     // this trunk's d loss / d head outputs
     // loss sums of this row group (recorded once: by the critic and by actor trunk 0)
-    if (tid == 0 && (critic || t == 0)) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < R; ++r) { s0 += ROWL[r]; s1 += ROWL[R + r]; }
-        float* ls = slab + d.total;
-        if (critic) ls[0] = s0;
-        else { ls[1] = s0; ls[2] = s1; }
+    if (tid < 64 && (critic || t == 0)) {   // first wave: R <= 64 row losses, one per lane
+        float s0 = tid < R ? ROWL[tid] : 0.f, s1 = (tid < R && !critic) ? ROWL[R + tid] : 0.f;
+        s0 = sg_wave_sum(s0); s1 = sg_wave_sum(s1);
+        if (tid == 0) {
+            float* ls = slab + d.total;
+            if (critic) ls[0] = s0;
+            else { ls[1] = s0; ls[2] = s1; }
+        }
     }
     float* g = slab + tr.off;
     // head weight / bias gradients (needs h2 before it is overwritten)
@@ -305,6 +367,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
     if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
     __syncthreads();
+    SG_PPO_STAMP(11);
     // dZ = (dY W) * (1 - h^2) in place over h; the bias gradient falls out of the epilogue registers
     auto dz_epilogue = [&](float* h, float* gb) {
         return [=](int tn, f32x4 (&acc)[MT][1]) {
@@ -325,11 +388,16 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     };
     sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, d.Hp, dz_epilogue(H2, g + tr.b2));
     __syncthreads();
+    SG_PPO_STAMP(12);
     sg_grad_tn<MT>(H2, ldH, H1, ldH, d.Hp, d.Hp, g + tr.w2, ldH, false);
     __syncthreads();
+    SG_PPO_STAMP(13);
     sg_layer_nn_t<MT>(H2, ldH, W + tr.w2, ldH, d.Hp, d.Hp, dz_epilogue(H1, g + tr.b1));
     __syncthreads();
+    SG_PPO_STAMP(14);
     sg_grad_tn<MT>(H1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, false);
+    __syncthreads();
+    SG_PPO_STAMP(15);
 }
 
 // grad[i] = sum over slabs; part[block] = sum of squares of this block's grads.  A block owns 64 consecutive

@@ -32,4 +32,10 @@ print("k_ppo_fwd phases, median cycles over", nb, "row groups:")
 for i, n in enumerate(names):
     print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
 print("   total       ", int(np.median(t[:, 5] - t[:, 0])))
+names = ["stage+rows", "loss", "head TN", "head NN", "W2 TN", "W2 NN", "W1 TN"]
+d = np.diff(t[:, 8:16], axis=1)
+print("k_ppo_bwd phases (trunk 0), median cycles over", nb, "row groups:")
+for i, n in enumerate(names):
+    print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
+print("   total       ", int(np.median(t[:, 15] - t[:, 8])))
 _lib.check(fn(agent.h, 0, None, 0))
