@@ -295,6 +295,41 @@ def test_disc_short_expert_is_an_error(sg):
         D.update_gail_dyn(Loader(np.zeros((5, 7), np.float32), 8), ro)
 
 
+@pytest.mark.parametrize("name", ["ckpt_policy_mlp", "ckpt_policy_split"])
+def test_checkpoint_interop_policy(sg, name, tmp_path):
+    """A reference-written `[actor_critic, ob_rms]` file -> device policy -> the reference's own outputs; and back out
+    to a file with the reference's layout (a2c/main.py:78-88,260-269)."""
+    import os
+
+    from helpers import GOLDEN
+    from simgan_amd import checkpoint as ck
+    g = load(name)
+    pol, ob_rms = ck.load_policy(os.path.join(GOLDEN, name + ".pt"))
+    assert type(pol).__name__ == ("Policy" if g["meta"]["kind"] == "mlp" else "SplitPolicy")
+    v, a, lp, _ = pol.act(g["obs"], None, None, deterministic=True)
+    assert_close(v, g["value"], what="value")
+    assert_close(a, g["action"], what="action")
+    assert_close(lp, g["logp"], what="log-prob")
+    assert (ob_rms is None) == (name == "ckpt_policy_split")
+    out = str(tmp_path / "saved.pt")
+    ck.save_policy(out, pol, ob_rms)
+    back = ck.read_reference_checkpoint(out)
+    assert np.array_equal(np.concatenate([x.reshape(-1) for x in back["state_dict"].values()]), g["flat"])
+
+
+def test_checkpoint_interop_discriminator(sg):
+    import os
+
+    from helpers import GOLDEN
+    from simgan_amd import checkpoint as ck
+    g = load("ckpt_disc")
+    D, ret_rms = ck.load_discriminator(os.path.join(GOLDEN, "ckpt_disc.pt"))
+    assert np.array_equal(D.get_flat_params(), g["flat"])
+    mm, vv, step = D.get_adam()
+    assert np.array_equal(mm, g["adam_m"]) and np.array_equal(vv, g["adam_v"]) and step == int(g["step"])
+    assert_close(D.returns.numpy() if hasattr(D.returns, "numpy") else D.returns, g["returns"], rtol=0, atol=0, what="returns")
+
+
 @pytest.mark.parametrize("name", ["relabel_tiny", "relabel_northstar"])
 def test_relabel_golden(sg, name):
     g = load(name)

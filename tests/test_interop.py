@@ -1,0 +1,139 @@
+"""CPU: the reference's file formats around the hot path -- whole-module checkpoints
+and the expert trajectory pickle -- against fixtures written by the reference itself (tools/gen_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, assert_close, load
+from oracle import oracle as orc
+from simgan_amd import checkpoint as ck
+from simgan_amd import expert as ex
+
+REFERENCE = "/root/reference"
+
+
+def _flat(sd):
+    return np.concatenate([v.reshape(-1) for v in sd.values()])
+
+
+@pytest.mark.parametrize("name", ["ckpt_policy_mlp", "ckpt_policy_split"])
+def test_read_reference_policy_checkpoint(name):
+    """Parsed with inert stand-in classes (no reference on the path); the weights drive the oracle to the outputs
+    the reference policy produced before it was saved."""
+    assert not any(m.startswith("third_party") for m in sys.modules), "the reference must not be importable here"
+    g = load(name)
+    m = g["meta"]
+    c = ck.read_reference_checkpoint(os.path.join(GOLDEN, name + ".pt"))
+    assert (c["kind"], c["obs_dim"], c["act_dim"], c["hidden"], c["num_feet"]) == (m["kind"], m["O"], m["A"], m["H"], m["f"])
+    assert np.array_equal(_flat(c["state_dict"]), g["flat"])
+    d = orc.dims(orc.KIND_MLP if m["kind"] == "mlp" else orc.KIND_SPLIT, m["O"], m["A"], m["H"], m["f"])
+    value, action, logp = orc.policy_act(d, g["flat"], g["obs"])      # no noise = dist.mode()
+    assert_close(value, g["value"], what="value")
+    assert_close(action, g["action"], what="deterministic action")
+    assert_close(logp, g["logp"], what="log-prob")
+    if name == "ckpt_policy_mlp":
+        assert_close(c["ob_rms"]["mean"], g["rms_mean"], rtol=0, atol=0, what="ob_rms.mean")
+        assert_close(c["ob_rms"]["var"], g["rms_var"], rtol=0, atol=0, what="ob_rms.var")
+        assert c["ob_rms"]["count"] == float(g["rms_count"])
+    else:
+        assert c["ob_rms"] is None
+
+
+def test_read_reference_discriminator_checkpoint():
+    g = load("ckpt_disc")
+    c = ck.read_reference_discriminator(os.path.join(GOLDEN, "ckpt_disc.pt"))
+    assert (c["input_dim"], c["hidden_dim"]) == (g["meta"]["F"], g["meta"]["Hd"])
+    assert np.array_equal(_flat(c["state_dict"]), g["flat"])
+    mm, vv, step = c["adam"]
+    assert np.array_equal(mm, g["adam_m"]) and np.array_equal(vv, g["adam_v"]) and step == int(g["step"])
+    assert np.array_equal(c["returns"], g["returns"])
+    assert c["ret_rms"]["count"] == pytest.approx(1e-4)
+
+
+@pytest.mark.parametrize("name", ["ckpt_policy_mlp", "ckpt_policy_split"])
+def test_written_checkpoint_round_trips(name, tmp_path):
+    g = load(name)
+    src = ck.read_reference_checkpoint(os.path.join(GOLDEN, name + ".pt"))
+    out = str(tmp_path / "again.pt")
+    ck.save_reference_checkpoint(out, src["kind"], src["state_dict"], src["ob_rms"])
+    assert not any(m.startswith("third_party") for m in sys.modules), "temporary class modules must be removed again"
+    back = ck.read_reference_checkpoint(out)
+    assert list(back["state_dict"]) == list(src["state_dict"])
+    assert np.array_equal(_flat(back["state_dict"]), g["flat"])
+    assert (back["kind"], back["obs_dim"], back["act_dim"], back["hidden"], back["num_feet"]) == \
+        (src["kind"], src["obs_dim"], src["act_dim"], src["hidden"], src["num_feet"])
+    if src["ob_rms"] is not None:
+        assert np.array_equal(back["ob_rms"]["mean"], src["ob_rms"]["mean"]) and back["ob_rms"]["count"] == src["ob_rms"]["count"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference checkout (development container only)")
+@pytest.mark.parametrize("name", ["ckpt_policy_mlp", "ckpt_policy_split"])
+def test_reference_loads_what_this_package_writes(name, tmp_path):
+    """In a subprocess (so this process never imports the reference): the reference's own `torch.load` +
+    `actor_critic.act(..., deterministic=True)` on a file written by save_reference_checkpoint."""
+    import subprocess
+    g = load(name)
+    src = ck.read_reference_checkpoint(os.path.join(GOLDEN, name + ".pt"))
+    out = str(tmp_path / "from_simgan_amd.pt")
+    ck.save_reference_checkpoint(out, src["kind"], src["state_dict"], None)
+    np.save(str(tmp_path / "obs.npy"), g["obs"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from tools.ref_import import import_reference\n"
+        "import_reference()\n"
+        f"actor_critic, ob_rms = torch.load({out!r}, map_location='cpu', weights_only=False)\n"
+        f"obs = torch.from_numpy(np.load({str(tmp_path / 'obs.npy')!r}))\n"
+        "with torch.no_grad():\n"
+        "    v, a, lp, _ = actor_critic.act(obs, None, None, deterministic=True)\n"
+        f"np.savez({str(tmp_path / 'out.npz')!r}, v=v.numpy(), a=a.numpy(), lp=lp.numpy(), cls=type(actor_critic).__module__)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = np.load(str(tmp_path / "out.npz"))
+    assert str(o["cls"]).startswith("third_party.a2c_ppo_acktr")
+    assert_close(o["v"], g["value"], rtol=1e-6, what="value from the reference on our file")
+    assert_close(o["a"], g["action"], rtol=1e-6, what="action")
+    assert_close(o["lp"], g["logp"], rtol=1e-6, what="log-prob")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "trained_models_hopper_bullet_new11")),
+                    reason="shipped behaviour policies live in the reference checkout")
+@pytest.mark.parametrize("rel,O,A", [("trained_models_hopper_bullet_new11/ppo/HopperURDFEnv-v3.pt", 11, 3),
+                                     ("trained_models_laika_bullet_70/ppo/LaikagoBulletEnv-v4.pt", 111, 12)])
+def test_reads_the_shipped_behaviour_policies(rel, O, A):
+    c = ck.read_reference_checkpoint(os.path.join(REFERENCE, rel))
+    assert (c["kind"], c["obs_dim"], c["act_dim"], c["hidden"]) == ("mlp", O, A, 64) and c["ob_rms"] is None
+    d = orc.dims(orc.KIND_MLP, O, A, 64, 1)
+    value, action, logp = orc.policy_act(d, _flat(c["state_dict"]), np.zeros((2, O), np.float32))
+    assert np.isfinite(value).all() and np.isfinite(action).all() and np.isfinite(logp).all()
+
+
+def test_expert_wire_format_matches_the_reference_helpers():
+    g = load("expert_trajs")
+    path = os.path.join(GOLDEN, "expert_trajs.pkl")
+    sas = ex.load_sas_wpast_from_pickle(path, downsample_freq=2, start_idx=g["start_idx"])
+    assert len(sas) == int(g["n_items"]) and np.array_equal(sas[0], g["first_item"])
+    merged = ex.select_and_merge_sas(sas, s_idx=np.array([0, 2]), a_idx=np.array([0, 1]))
+    assert merged.dtype == np.float64 and np.array_equal(merged, g["merged"])
+    one = ex.select_and_merge_sas([x[0] for x in sas], s_idx=np.array([0]), a_idx=np.array([0]))
+    assert np.array_equal(one, g["one"])
+    mat, n = ex.expert_matrix(path, s_idx=(0, 2), a_idx=(0, 1), downsample_freq=2, start_idx=g["start_idx"])
+    assert mat.dtype == np.float32 and n == merged.shape[0] and np.array_equal(mat, merged.astype(np.float32))
+    assert ex.gail_tar_length(n, 3, 2) == n / 3 * 2
+
+
+def test_expert_loader_handles_state_and_action_of_different_width_and_subsets():
+    """The collector's tuples mix state vectors and (shorter) action vectors; load_num_trajs stops after that many."""
+    r = np.random.RandomState(0)
+    trajs = {t: [[list(r.randn(5)) for _ in range(2)] + [list(r.randn(3)) for _ in range(2)] + [list(r.randn(5))]
+                 for _ in range(4 + t)] for t in range(3)}
+    sas = ex.load_sas_wpast_from_pickle(trajs)
+    assert [a.shape for a in sas] == [(15, 5), (15, 5), (15, 3), (15, 3), (15, 5)]
+    m = ex.select_and_merge_sas(sas)
+    assert m.shape == (15, 13) and np.array_equal(m[:, 5:8], sas[2]) and np.array_equal(m[:, 8:], sas[4])
+    assert ex.load_sas_wpast_from_pickle(trajs, load_num_trajs=2)[0].shape == (9, 5)
+    sub = ex.load_sas_wpast_from_pickle(trajs, downsample_freq=3, start_idx=[0, 1, 2])
+    assert sub[0].shape[0] == len(range(0, 4, 3)) + len(range(1, 5, 3)) + len(range(2, 6, 3))

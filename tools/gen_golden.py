@@ -390,6 +390,74 @@ def gen_iteration(name, kind, O, A, H, f, F, Hd, T, N, B, Ne, E, M, Ed, iters, s
                          gail_tar_length=gail_tar_length, gamma=0.99, gae_lambda=0.95), **out)
 
 
+# ------------------------------------------- G. checkpoint files and the expert wire format
+def gen_checkpoints():
+    """Whole-module checkpoints exactly as the reference writes them (a2c/main.py:260-269,
+    a2c/main_gail_dyn_ppo.py:319): the .pt files are data (pickled objects by reference to class names)."""
+    import pickle
+    from torch.utils.data import DataLoader, TensorDataset
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    g = torch.Generator().manual_seed(77)
+    # MLP policy + observation statistics, legacy container (what the shipped trained_models_*/ppo/*.pt use)
+    p = make_policy("mlp", 11, 3, 64, 1, 700)
+    rms = ns.RunningMeanStd(shape=(11,))
+    rms.update(np.random.RandomState(3).randn(50, 11) * 2.0 + 0.5)
+    torch.save([p, rms], os.path.join(out_dir, "ckpt_policy_mlp.pt"), _use_new_zipfile_serialization=False)
+    obs = torch.randn(6, 11, generator=g)
+    with torch.no_grad():
+        v, a, lp, _ = p.act(obs, None, None, deterministic=True)
+    save("ckpt_policy_mlp", meta=meta(kind="mlp", O=11, A=3, H=64, f=1), flat=flat_params(p), obs=obs.numpy(), value=v.numpy(),
+         action=a.numpy(), logp=lp.numpy(), rms_mean=rms.mean, rms_var=rms.var, rms_count=np.float64(rms.count))
+    # split policy, zip container (torch >= 1.6 default)
+    p = make_policy("split", 14, 7, 32, 1, 710)
+    torch.save([p, None], os.path.join(out_dir, "ckpt_policy_split.pt"))
+    obs = torch.randn(5, 14, generator=g)
+    with torch.no_grad():
+        v, a, lp, _ = p.act(obs, None, None, deterministic=True)
+    save("ckpt_policy_split", meta=meta(kind="split", O=14, A=7, H=32, f=1), flat=flat_params(p), obs=obs.numpy(),
+         value=v.numpy(), action=a.numpy(), logp=lp.numpy())
+    # discriminator after one epoch (Adam state, running returns)
+    torch.manual_seed(720)
+    D = ns.Discriminator(7, 16, "cpu")
+    expert = torch.randn(24, 7, generator=g)
+    ro = ns.RolloutStorage(4, 8, (3,), ns.Box(shape=(2,)), 1, 7)
+    fill_rollout(ro, 4, 8, 3, 2, 7, 721)
+    D.update_gail_dyn(DataLoader(TensorDataset(expert), batch_size=8, shuffle=True, drop_last=True), ro)
+    D.predict_reward_combined(ro.obs_feat[1], 0.99, ro.masks[0], offset=0.1)
+    torch.save(D, os.path.join(out_dir, "ckpt_disc.pt"))
+    ps = list(D.trunk.parameters())
+    st = D.optimizer.state
+    save("ckpt_disc", meta=meta(F=7, Hd=16), flat=flat_params(D.trunk),
+         adam_m=np.concatenate([st[q]["exp_avg"].numpy().reshape(-1) for q in ps]),
+         adam_v=np.concatenate([st[q]["exp_avg_sq"].numpy().reshape(-1) for q in ps]),
+         step=np.int64(int(st[ps[0]]["step"])), returns=D.returns.numpy())
+    # expert trajectories in the collector's wire format (a2c/collect_tarsim_traj.py:218-265): L = 3 past steps
+    r = np.random.RandomState(11)
+    trajs = {}
+    for ti in range(3):
+        rows = []
+        for _ in range(5 + ti):
+            rows.append([list(r.randn(4)) for _ in range(3)] + [list(r.randn(4)) for _ in range(3)] + [list(r.randn(4))])  # equal widths: the reference stacks the tuples with np.array, which modern numpy only accepts for a regular shape
+        trajs[ti] = rows
+    blob = pickle.dumps(trajs, protocol=2)
+    with open(os.path.join(out_dir, "expert_trajs.pkl"), "wb") as f:
+        f.write(blob)
+    gu = ns.gan_utils
+    _REC.clear()
+    torch.manual_seed(5)
+    ri = torch.randint
+    drawn = []
+    torch.randint = lambda *a_, **k_: (drawn.append(ri(*a_, **k_)) or drawn[-1])
+    try:
+        sas = gu.load_sas_wpast_from_pickle(os.path.join(out_dir, "expert_trajs.pkl"), downsample_freq=2)
+    finally:
+        torch.randint = ri
+    merged = gu.select_and_merge_sas(sas, s_idx=np.array([0, 2]), a_idx=np.array([0, 1]))
+    one = gu.select_and_merge_sas([np.asarray(x[0]) for x in sas], s_idx=np.array([0]), a_idx=np.array([0]))
+    save("expert_trajs", start_idx=drawn[0].numpy().astype(np.int64), merged=merged, one=one,
+         n_items=np.int64(len(sas)), first_item=np.asarray(sas[0]))
+
+
 if __name__ == "__main__":
     gen_policy("policy_mlp_tiny", "mlp", 5, 2, 8, 1, 16, 100)
     gen_policy("policy_mlp_northstar", "mlp", 47, 12, 64, 1, 24, 110)
@@ -413,4 +481,5 @@ if __name__ == "__main__":
     gen_relabel("relabel_tiny", F=7, Hd=16, T=6, N=5, seed=400)
     gen_relabel("relabel_northstar", F=86, Hd=100, T=8, N=32, seed=410)
     gen_iteration("iter_mlp", "mlp", 47, 12, 64, 1, F=86, Hd=100, T=8, N=16, B=32, Ne=200, E=2, M=2, Ed=2, iters=2, seed=500)
+    gen_checkpoints()
     gen_iteration("iter_split", "split", 14, 7, 100, 1, F=25, Hd=100, T=8, N=16, B=32, Ne=100, E=2, M=2, Ed=2, iters=2, seed=510)

@@ -110,9 +110,10 @@ def import_reference():
     from third_party.a2c_ppo_acktr.storage import RolloutStorage  # noqa
     from third_party.a2c_ppo_acktr.baselines.common.running_mean_std import RunningMeanStd  # noqa
     from third_party.a2c_ppo_acktr import utils as a2c_utils  # noqa
+    from my_pybullet_envs import utils as gan_utils  # noqa  (expert trajectory helpers; pybullet itself is a stand-in)
     ns = types.SimpleNamespace(PPO=algo.PPO, Discriminator=gail.Discriminator, Policy=Policy,
                                SplitPolicy=SplitPolicy, RolloutStorage=RolloutStorage,
-                               RunningMeanStd=RunningMeanStd, Box=Box, a2c_utils=a2c_utils)
+                               RunningMeanStd=RunningMeanStd, Box=Box, a2c_utils=a2c_utils, gan_utils=gan_utils)
     return ns
 
 
