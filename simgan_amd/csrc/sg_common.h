@@ -199,34 +199,23 @@ struct sg_disc {
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
 };
 
-// Device-side optimizer scalars (float): kept in device memory so captured/queued launches never
-// depend on host-side kernel arguments that change between steps.
+// Device-side optimizer scalars: kept in device memory so queued / graph-replayed launches never depend on
+// host-side kernel arguments that change between steps.  Adam step t = t0 + (the launch's 1-based index within
+// its epoch / update); its bias corrections (torch computes them in Python doubles) sit in slot t & 1, written by
+// one spare lane of an earlier kernel (sg_opt_prepare) so nothing on a step's critical path evaluates pow().
 struct SgOptState {
     float lr;
-    float step;       // Adam t (exact in fp32 up to 2^24 steps)
-    float step_size;  // lr / (1 - beta1^t), refreshed by sg_opt_advance()
-    float bc2_sqrt;   // sqrt(1 - beta2^t)
-    // discriminator: the same two scalars for step t in slot t & 1, written one step ahead by a spare lane of
-    // the previous optimizer kernel (sg_opt_prepare) so nothing on the step's critical path evaluates pow()
-    float step_size2[2];
-    float bc2_sqrt2[2];
-    int t0;           // discriminator: Adam steps completed before the current epoch (k_opt_commit adds an epoch's
-    int pad[3];       // steps at its end), so per-step kernel arguments do not change between epochs and the
-};                    // epoch's launches can be replayed as a hipGraph
+    float reserved[3];
+    float step_size2[2];   // lr / (1 - beta1^t)
+    float bc2_sqrt2[2];    // sqrt(1 - beta2^t)
+    int t0;                // Adam steps completed before the current epoch / update (k_opt_commit adds to it)
+    int pad[3];
+};
 
 #ifdef __HIPCC__
 // tiny clears stay on the library's own launch path (the runtime's fill path is a separate blit kernel)
 __attribute__((unused)) static __global__ void k_zero_f64(double* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.0;
-}
-// t += 1 and the bias-correction scalars of torch.optim.Adam (Python doubles in torch); called by
-// ONE thread of the kernel that precedes the Adam kernel, so the Adam kernel only reads them.
-__device__ __forceinline__ void sg_opt_advance(SgOptState* st) {
-    const float t = st->step + 1.0f;
-    st->step = t;
-    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
-    st->step_size = (float)((double)st->lr / bc1);
-    st->bc2_sqrt = (float)sqrt(bc2);
 }
 // End of an epoch / update: the steps just taken become part of the base count.
 __attribute__((unused)) static __global__ void k_opt_commit(SgOptState* st, int n_steps) { st->t0 += n_steps; }

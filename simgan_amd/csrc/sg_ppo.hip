@@ -9,6 +9,9 @@
 //   k_adv_stats x3                                   advantages, global mean / unbiased std
 //   per epoch:   k_ppo_epoch_gather                  permuted copy of the rollout
 //   per step:    k_ppo_fwd -> k_ppo_bwd -> k_ppo_reduce [-> all-reduce -> k_sumsq] -> k_ppo_adam
+//   then         k_opt_commit                        Adam's step base += E*M
+// Everything from the first epoch gather on is captured into a hipGraph once and replayed per update (single GPU;
+// with a communicator the RCCL calls are issued directly between the kernels).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
