@@ -410,14 +410,19 @@ __device__ __forceinline__ void sg_stage(float* lds, const float* __restrict__ g
 // now, commit them to LDS later, so the memory round trip overlaps whatever is placed in between
 // (the dependent index->row gather of a minibatch).  The tail beyond U*blockDim, if any, is copied
 // by sg_stage_commit itself.
+// The loads are buffer loads: the hardware range-checks every lane against the n4*16-byte extent and returns
+// zeros beyond it, so there is no per-load guard for the compiler to turn into a branch (which would make
+// each request wait for the previous one).
+typedef unsigned int sg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sg_buffer_load4(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    const sg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0);
+    return float4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+}
 template <int U>
 __device__ __forceinline__ void sg_stage_issue(float4 (&v)[U], const float* __restrict__ g, int n4) {
-    const float4* src = reinterpret_cast<const float4*>(g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, n4 * 16, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int i = threadIdx.x + u * blockDim.x;
-        v[u] = i < n4 ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < U; ++u) v[u] = sg_buffer_load4(rsrc, (int)(threadIdx.x + u * blockDim.x) * 16);
 }
 template <int U>
 __device__ __forceinline__ void sg_stage_commit(float* lds, const float4 (&v)[U], const float* __restrict__ g, int n4) {

@@ -61,9 +61,9 @@ static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT) {
                             ((R * d.A + 3) & ~3) + 7 * R);
 }
 
-// shape-specialised instances for the shipped configurations at 32-row
-// tiles, plus run-time-shape fallbacks
-#define SG_PPO_SHAPES(X) X(2, 3, 4) /* north-star: obs 47, h64 */ X(2, 1, 7) /* HopperCombined: obs 14, h100 */ \
+// shape-specialised instances for the shipped configurations at the row-group
+// size the launch heuristic picks for them, plus run-time-shape fallbacks
+#define SG_PPO_SHAPES(X) X(1, 3, 4) X(2, 3, 4) /* north-star: obs 47, h64 */ X(2, 1, 7) /* HopperCombined: obs 14, h100 */ \
                          X(2, 4, 7) /* LaikagoCombined: obs 64, h100 */ X(2, 7, 4) /* Laikago refinement: obs 111, h64 */
 
 static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {

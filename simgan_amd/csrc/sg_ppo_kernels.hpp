@@ -98,11 +98,13 @@ template <int MT, int KO, int KH>
 __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
-    SgPolicyDesc d = a.d;
-    if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
+    // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
+    // with compile-time KO/KH the four extents below fold to constants
+    const SgPolicyDesc& d = a.d;
+    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
     const int t = blockIdx.y, tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
-    const int ldO = d.ldO, ldH = d.ldH, ldP = a.ldP;
+    const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP;
     float* W = smem;
     float* X = W + a.wbuf_floats;
     float* H1 = X + R * ldO;
@@ -127,21 +129,21 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
     float* gH1 = a.H1[t] + (size_t)row0 * ldH;
     float* gH2 = a.H2[t] + (size_t)row0 * ldH;
     float* gOUT = a.OUT[t] + (size_t)row0 * ldP;
-    sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp, [&](int r, int c, float v) {
+    sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b1[c]);
         H1[r * ldH + c] = h;
         gH1[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(3);
-    sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp, [&](int r, int c, float v) {
+    sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b2[c]);
         H2[r * ldH + c] = h;
         gH2[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(4);
-    sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
+    sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
     __syncthreads();
     SG_PPO_STAMP(5);
 }
@@ -155,13 +157,15 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
         return;
     }
     constexpr int R = 16 * MT;
-    SgPolicyDesc d = a.d;
-    if (KO > 0 && KH > 0) { d.Op = 16 * KO; d.ldO = d.Op + 4; d.Hp = 16 * KH; d.ldH = d.Hp + 4; }
+    // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
+    // with compile-time KO/KH the four extents below fold to constants
+    const SgPolicyDesc& d = a.d;
+    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
     const int t = blockIdx.y, tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
     const bool critic = t == d.n_trunks - 1;
     const bool mlp = d.kind == SG_POLICY_MLP;
-    const int ldO = d.ldO, ldH = d.ldH, ldP = a.ldP, A = d.A;
+    const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP, A = d.A;
     // LDS image of the trunk block from w2 on (w1/b1 are not needed going backward)
     float* Wimg = smem;
     const float* W = Wimg - tr.w2;                 // so that W + tr.<off> addresses the block as usual
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     }
     float* g = slab + tr.off;
     // head weight / bias gradients (needs h2 before it is overwritten)
-    sg_grad_tn<MT>(dout, ldP, H2, ldH, tr.Pp, d.Hp, g + tr.wh, ldH, false);
+    sg_grad_tn<MT>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
     sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
     if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
     __syncthreads();
@@ -386,16 +390,16 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
             if (lq == 0) gb[c] = sb;
         };
     };
-    sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, d.Hp, dz_epilogue(H2, g + tr.b2));
+    sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_epilogue(H2, g + tr.b2));
     __syncthreads();
     SG_PPO_STAMP(12);
-    sg_grad_tn<MT>(H2, ldH, H1, ldH, d.Hp, d.Hp, g + tr.w2, ldH, false);
+    sg_grad_tn<MT>(H2, ldH, H1, ldH, Hp, Hp, g + tr.w2, ldH, false);
     __syncthreads();
     SG_PPO_STAMP(13);
-    sg_layer_nn_t<MT>(H2, ldH, W + tr.w2, ldH, d.Hp, d.Hp, dz_epilogue(H1, g + tr.b1));
+    sg_layer_nn_t<MT>(H2, ldH, W + tr.w2, ldH, Hp, Hp, dz_epilogue(H1, g + tr.b1));
     __syncthreads();
     SG_PPO_STAMP(14);
-    sg_grad_tn<MT>(H1, ldH, X, ldO, d.Hp, d.Op, g + tr.w1, ldO, false);
+    sg_grad_tn<MT>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
     __syncthreads();
     SG_PPO_STAMP(15);
 }
