@@ -189,6 +189,8 @@ struct sg_disc {
     hipGraphExec_t epoch_graph = nullptr;   // one epoch of update steps, captured once and replayed
     uint64_t epoch_graph_key[12] = {0};
     float* d_wT = nullptr;         // weight images W1 | W2 | W2^T | W1^T of k_disc_chain4, maintained by k_disc_wgrad
+    float *d_erows = nullptr, *d_prows = nullptr;   // the epoch's expert / policy rows in consumption order
+    int64_t erows_cap = 0, prows_cap = 0;
     float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
     int64_t rows_cap = 0;
     double* d_loss_acc = nullptr;

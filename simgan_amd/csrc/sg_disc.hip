@@ -227,7 +227,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
-    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT};
+    float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT, d->d_erows, d->d_prows};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
@@ -354,6 +354,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     SG_TRY(ensure_cap(&d->d_eperm, &d->eperm_cap, d->n_expert, ctx->stream));
     SG_TRY(ensure_cap(&d->d_pperm, &d->pperm_cap, TN, ctx->stream));
     SG_TRY(ensure_cap(&d->d_alpha, &d->alpha_cap, (int64_t)n_d * batch_size, ctx->stream));
+    SG_TRY(ensure_cap(&d->d_erows, &d->erows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // +1: the last step's
+    SG_TRY(ensure_cap(&d->d_prows, &d->prows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // "next" pointers stay in range
     d->rng_calls += 1;
     // expert permutation / alpha are GLOBAL (identical on every rank); the policy permutation is per rank
     if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
@@ -410,6 +412,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     // host thread can no longer starve the GPU in the middle of an epoch.
     auto enqueue_epoch = [&]() -> int {
         hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, ctx->stream, d->d_loss_acc, 3);
+        {   // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch (sharded mode)
+            EpochRowsArgs er;
+            er.expert = d->d_expert; er.feat = a.next_feat; er.eperm = d->d_eperm; er.pperm = d->d_pperm;
+            er.erows = d->d_erows; er.prows = d->d_prows; er.n_d = n_d; er.B_loc = B_loc; er.batch_size = batch_size;
+            er.roff = sharded ? ctx->rank * B_loc : 0; er.F = dd.F;
+            hipLaunchKernelGGL(k_disc_epoch_rows, dim3(2048), dim3(256), 0, ctx->stream, er);
+        }
         for (int k = 0; k < n_d; ++k) {
             // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
             const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
@@ -419,14 +428,15 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             a.ops = stacks[k & 1];
             wa.ops = a.ops;
             PregatherArgs pg;
-            pg.expert = d->d_expert; pg.next_feat = a.next_feat; pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp;
-            pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st;
+            pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp; pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st;
+            const size_t step_rows = (size_t)B_loc * dd.F;
             wa.k1 = k + 1;
             if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
-                pg.eperm = a.eperm; pg.pperm = a.pperm; pg.alpha = a.alpha; pg.ops = a.ops;
+                pg.erows = d->d_erows; pg.prows = d->d_prows; pg.alpha = a.alpha; pg.ops = a.ops;
                 hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
             }
-            pg.eperm = a.eperm + batch_size; pg.alpha = a.alpha + batch_size; pg.pperm = a.pperm + B_loc;
+            pg.erows = d->d_erows + (size_t)(k + 1) * step_rows; pg.prows = d->d_prows + (size_t)(k + 1) * step_rows;
+            pg.alpha = a.alpha + batch_size;
             pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
             wa.next = pg;
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
@@ -448,7 +458,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     } else {
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
-                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin, (uint64_t)ops_f, 0x5647ull};
+                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin, (uint64_t)ops_f,
+                                  (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
             hipGraph_t graph = nullptr;

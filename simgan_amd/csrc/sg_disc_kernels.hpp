@@ -95,19 +95,36 @@ static size_t disc_ops_floats(const SgDiscDesc& d, int G) {
 // Input rows of ONE chain workgroup of the NEXT step, gathered by permutation index into the right
 // operand stack it will read them from: rows [32g, 32g+32) = 16 expert + 16 policy rows for BCE
 // workgroup g (j < G), rows [3nb+16g, +16) = the alpha-mixed rows for mixup workgroup g (j >= G).
-// The index -> row dependent round trips (a2c/storage.py:168-185 gather, DataLoader batch,
-// a2c/algo/gail.py:72-75 mixup) thereby run beside the previous step's weight-gradient tiles
-// instead of at the head of the serial chain.  Columns [F, Fp) are written as zeros.
+// The rows come from the epoch's permuted copies (k_disc_epoch_rows: a2c/storage.py:168-185 gather and the
+// DataLoader's shuffled batches, resolved once per epoch), so this is one contiguous read per row, no index
+// chase; the mixup (a2c/algo/gail.py:72-75) is formed here.  It runs beside the previous step's weight-gradient
+// tiles instead of at the head of the serial chain.  Columns [F, Fp) are written as zeros.
 struct PregatherArgs {
-    const float* expert;
-    const float* next_feat;
-    const int64_t* eperm;
-    const int64_t* pperm;
-    const float* alpha;
+    const float* erows;   // this step's expert rows [B][F] in batch order
+    const float* prows;   // this step's policy rows [B][F]
+    const float* alpha;   // [B]
     float* ops;     // operand stacks of the step being prepared
     int B, G, F, Fp, ldF, Hp;
     SgOptState* st; // the first step's Adam scalars are prepared alongside (one lane of k_disc_pregather)
 };
+
+// Once per epoch: expert and policy rows in the order the epoch's steps consume them.
+struct EpochRowsArgs {
+    const float *expert, *feat;
+    const int64_t *eperm, *pperm;
+    float *erows, *prows;
+    int n_d, B_loc, batch_size, roff, F;
+};
+__global__ __launch_bounds__(256) void k_disc_epoch_rows(EpochRowsArgs a) {
+    const int64_t total = (int64_t)a.n_d * a.B_loc * a.F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / a.F;
+        const int c = (int)(i - row * a.F);
+        const int k = (int)(row / a.B_loc), b = (int)(row - (int64_t)k * a.B_loc);
+        a.erows[i] = a.expert[(size_t)a.eperm[(size_t)k * a.batch_size + a.roff + b] * a.F + c];
+        a.prows[i] = a.feat[(size_t)a.pperm[(size_t)k * a.B_loc + b] * a.F + c];
+    }
+}
 
 __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j) {
     const int nb = 16 * p.G, Kt = 4 * nb;
@@ -128,10 +145,10 @@ __device__ __forceinline__ void sg_disc_pregather(const PregatherArgs& p, int j)
             const int b = g * 16 + (r & 15);
             v[u] = 0.f;
             if (i < rows * Fp && b < p.B && c < F) {
-                if (bce) v[u] = (r < 16) ? p.expert[(size_t)p.eperm[b] * F + c] : p.next_feat[(size_t)p.pperm[b] * F + c];
+                if (bce) v[u] = (r < 16) ? p.erows[(size_t)b * F + c] : p.prows[(size_t)b * F + c];
                 else {
                     const float al = p.alpha[b];
-                    v[u] = al * p.expert[(size_t)p.eperm[b] * F + c] + (1.f - al) * p.next_feat[(size_t)p.pperm[b] * F + c];
+                    v[u] = al * p.erows[(size_t)b * F + c] + (1.f - al) * p.prows[(size_t)b * F + c];
                 }
             }
         }
@@ -727,6 +744,8 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         // waves split the stacked rows in 16-row chunks dealt round-robin; within a chunk MFMA step s takes
         // rows 4s..4s+3 (k = lq), so one load instruction of a wave covers 256 contiguous bytes
         const int n_chunks = Kt >> 4;
+        const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, Kt * 64, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rr), 0, Kt * 64, 0x00020000);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, alt = acc;
         for (int c0 = wave; c0 < n_chunks; c0 += 4 * nw) {       // up to 4 chunks = 32 loads in flight per lane
             float x[4][4], y[4][4];
@@ -735,10 +754,9 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int c = c0 + cc * nw;
-                    const int r = 16 * c + 4 * s + lq;
-                    const bool in = c < n_chunks;
-                    x[cc][s] = in ? L[(size_t)r * 16 + li] : 0.f;
-                    y[cc][s] = in ? Rr[(size_t)r * 16 + li] : 0.f;
+                    const int r = 16 * c + 4 * s + lq;   // chunks past the slab read as zero (buffer range check)
+                    x[cc][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rL, (r * 16 + li) * 4, 0, 0));
+                    y[cc][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, (r * 16 + li) * 4, 0, 0));
                 }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
@@ -781,6 +799,11 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         const float4 sc = *reinterpret_cast<const float4*>(a.st->step_size2);
         const bool odd = (a.st->t0 + a.k1) & 1;
         const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
+        // the element's parameter and moments are requested with the partials: one memory round trip per block
+        const bool is_param = wave == 0 && i < 3 * Hp + 1 && !a.grad_out;
+        const int pidx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
+        float pv = 0.f, pm = 0.f, pvv = 0.f;
+        if (is_param) { pv = a.params[pidx]; pm = a.m[pidx]; pvv = a.v[pidx]; }
         float g = 0.f;
         if (i < NE) {
             for (int s0 = wave; s0 < nparts; s0 += 16 * nw) {   // 16 loads in flight per lane: one round trip at batch 128
@@ -800,9 +823,15 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
             g = 0.f;
             for (int w = 0; w < nw; ++w) g += red[w][lane];
             if (i < 3 * Hp + 1) {
-                const int idx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
-                if (a.grad_out) a.grad_out[idx] = g;
-                else sg_adam_apply(a.params + idx, a.m + idx, a.v + idx, g, step_size, bc2_sqrt, a.eps);
+                if (a.grad_out) a.grad_out[pidx] = g;
+                else {
+                    pm = pm + (g - pm) * (float)(1.0 - 0.9);
+                    pvv = pvv * (float)0.999 + (float)(1.0 - 0.999) * g * g;
+                    const float denom = sqrtf(pvv) / bc2_sqrt + a.eps;
+                    a.params[pidx] = pv - step_size * (pm / denom);
+                    a.m[pidx] = pm;
+                    a.v[pidx] = pvv;
+                }
             }
             // loss_expert, loss_policy, loss_gp sums sit in elements 3Hp+1..3 = lanes l0+1..l0+3 of the last block
             const int l0 = (3 * Hp) & 63;
