@@ -335,7 +335,10 @@ __device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float* p = G + (4 * lq + r) * ldg + 16 * j + li;
-            *p = accumulate ? *p + acc[j][r] : acc[j][r];
+            // a fresh gradient panel is written once and read by a later kernel: a streaming store lets it drain
+            // to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back
+            if (accumulate) *p = *p + acc[j][r];
+            else __builtin_nontemporal_store(acc[j][r], p);
         }
 }
 

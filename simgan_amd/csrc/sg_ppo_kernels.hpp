@@ -44,10 +44,11 @@ struct PpoArgs {
     int wbuf_floats;
     long long* dbg;       // optional phase timestamps [block][16] (test hook), NULL in production
     SgOptState* st;       // k_ppo_bwd: one spare lane prepares this step's Adam scalars (step st->t0 + k1)
-    int k1, G;            // 1-based step index within the update; row groups (blockIdx.x == G is the spare block)
+    int k1, G;            // 1-based step index within the update; row groups (k_ppo_bwd: blockIdx.x == 0 is the spare block)
 };
 
 #define SG_PPO_STAMP(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[blockIdx.x * 16 + (n)] = clock64(); } while (0)
+#define SG_PPO_WALL(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y < 2) a.dbg[(blockIdx.x + 512 * blockIdx.y) * 16 + (n)] = wall_clock64(); } while (0)
 
 struct EpochGatherArgs {
     const float *obs, *actions, *old_logp, *adv, *vpred, *ret;
@@ -152,10 +153,13 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
 template <int MT, int KO, int KH>
 __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x == a.G) {   // spare block: the double-precision pow() of Adam's bias corrections, off every
-        if (blockIdx.y == 0 && threadIdx.x == 0) sg_opt_prepare(a.st, a.st->t0 + a.k1);   // row group's critical path
+    // spare block (dispatched first, so it runs beside the row groups, not after them): the double-precision pow()
+    // of Adam's bias corrections, off every row group's critical path
+    if (blockIdx.x == 0) {
+        if (blockIdx.y == 0 && threadIdx.x == 0) sg_opt_prepare(a.st, a.st->t0 + a.k1);
         return;
     }
+    const int bx = blockIdx.x - 1;   // row group
     constexpr int R = 16 * MT;
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
@@ -179,10 +183,11 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     float* SC = ACT + ((R * A + 3) & ~3);          // [4][R]
     float* ROWL = SC + 4 * R;                      // [2][R]
     int* VALID = reinterpret_cast<int*>(ROWL + 2 * R);
-    const int row0 = blockIdx.x * R;
-    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    const int row0 = bx * R;
+    float* slab = a.slabs + (size_t)bx * a.slab_stride;
 
     SG_PPO_STAMP(8);
+    SG_PPO_WALL(6);
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
     sg_stage_issue<12>(wv, a.params + tr.off + tr.w2, wfl / 4);
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     sg_grad_tn<MT>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
     __syncthreads();
     SG_PPO_STAMP(15);
+    SG_PPO_WALL(7);
 }
 
 // grad[i] = sum over slabs; part[block] = sum of squares of this block's grads.  A block owns 64 consecutive

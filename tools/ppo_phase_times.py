@@ -22,11 +22,13 @@ fn.argtypes = [_lib.H, C.c_int, C.POINTER(C.c_longlong), C.c_int]
 agent.update(ro)
 _lib.check(fn(agent.h, 1, None, 0))
 agent.update(ro)
-nb = 64
+nb = 1024
 buf = (C.c_longlong * (16 * nb))()
 _lib.check(fn(agent.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 16)
 names = ["issue+rows", "commit+sync", "L1", "L2", "head"]
+t1 = t[512:]
+t = t[:256]
 d = np.diff(t[:, :6], axis=1)
 print("k_ppo_fwd phases, median cycles over", nb, "row groups:")
 for i, n in enumerate(names):
@@ -39,3 +41,13 @@ for i, n in enumerate(names):
     print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
 print("   total       ", int(np.median(t[:, 15] - t[:, 8])))
 _lib.check(fn(agent.h, 0, None, 0))
+
+st, en = t[:, 6], t[:, 7]     # wall clock, 100 MHz, comparable across CUs
+ok = st > 0
+print(f"k_ppo_bwd trunk-0 blocks with stamps: {int(ok.sum())}; first block start -> last block start {10 * int(st[ok].max() - st[ok].min())} ns, "
+      f"first start -> last end {10 * int(en[ok].max() - st[ok].min())} ns, median block {10 * int(np.median(en[ok] - st[ok]))} ns")
+st1, en1 = t1[:, 6], t1[:, 7]
+ok1 = st1 > 0
+if ok1.any():
+    print(f"k_ppo_bwd trunk-1 blocks: {int(ok1.sum())}; start {10 * int(st1[ok1].min() - st[ok].min())}..{10 * int(st1[ok1].max() - st[ok].min())} ns "
+          f"after the first trunk-0 block, last end {10 * int(en1[ok1].max() - st[ok].min())} ns, median block {10 * int(np.median(en1[ok1] - st1[ok1]))} ns")
