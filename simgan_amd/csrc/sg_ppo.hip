@@ -55,9 +55,13 @@ static size_t ppo_fwd_lds(const SgPolicyDesc& d, int MT) {
     const int R = 16 * MT;
     return sizeof(float) * ((size_t)max_trunk_floats(d) + R * d.ldO + 2 * R * d.ldH);
 }
+static bool ppo_fused(const SgPolicyDesc& d, int MT) {
+    const char* e = getenv("SG_PPO_FUSED");
+    return d.kind == SG_POLICY_MLP && MT <= 2 && !(e && !strcmp(e, "0"));
+}
 static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT) {
     const int R = 16 * MT;
-    return sizeof(float) * ((size_t)max_bwd_floats(d) + R * d.ldO + 2 * R * d.ldH + 2 * R * stack_ldP(d) +
+    return sizeof(float) * ((size_t)(ppo_fused(d, MT) ? max_trunk_floats(d) : max_bwd_floats(d)) + R * d.ldO + 2 * R * d.ldH + 2 * R * stack_ldP(d) +
                             ((R * d.A + 3) & ~3) + 7 * R);
 }
 
@@ -77,9 +81,16 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
     else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<2, 0, 0>), grid, block, lds, pa);
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
 }
-static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
+static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(256);
+    if (fused) {   // Policy (independent actor / critic trunks): forward recomputed inside, no k_ppo_fwd launch
+        if (MT == 1 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 3, 4, true>), grid, block, lds, pa); return; }
+        if (MT == 2 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 3, 4, true>), grid, block, lds, pa); return; }
+        if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true>), grid, block, lds, pa);
+        else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 0, 0, true>), grid, block, lds, pa);
+        return;
+    }
 #define SG_CASE(mt, o, h) \
     if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_SHAPES(SG_CASE)
@@ -278,6 +289,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         pa.OUT[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * ldP;
     }
     const int wb_f = max_trunk_floats(d), wb_b = max_bwd_floats(d);
+    const bool fused = ppo_fused(d, MT);
     const size_t lds_f = ppo_fwd_lds(d, MT), lds_b = ppo_bwd_lds(d, MT);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
@@ -293,11 +305,13 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
             for (int k = 0; k < M; ++k) {
                 const size_t rb = (size_t)k * mb;
                 pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
-                pa.wbuf_floats = wb_f;
-                launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
-                pa.wbuf_floats = wb_b;
+                if (!fused) {
+                    pa.wbuf_floats = wb_f;
+                    launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
+                }
+                pa.wbuf_floats = fused ? wb_f : wb_b;
                 pa.k1 = e * M + k + 1;
-                launch_ppo_bwd(ctx, MT, d, dim3(G + 1, d.n_trunks), lds_b, pa);
+                launch_ppo_bwd(ctx, MT, d, dim3(G + 1, d.n_trunks), lds_b, pa, fused);
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
                           d.total, a->d_grad, a->d_part);
                 if (ctx->use_comm) {
@@ -326,7 +340,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             hipGraph_t graph = nullptr;

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
 }
 
 // -------------------------------------------------------------------------------- backward
-template <int MT, int KO, int KH>
+// FUSED (Policy: the actor and critic trunks do not depend on each other's outputs): the workgroup stages the
+// whole trunk, recomputes the forward on its own rows in LDS and goes straight on to the loss -- no k_ppo_fwd
+// launch, no activation stacks written, flushed and read back (5 MB per step at the north-star shape).
+template <int MT, int KO, int KH, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // spare block (dispatched first, so it runs beside the row groups, not after them): the double-precision pow()
@@ -170,10 +173,11 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     const bool critic = t == d.n_trunks - 1;
     const bool mlp = d.kind == SG_POLICY_MLP;
     const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP, A = d.A;
-    // LDS image of the trunk block from w2 on (w1/b1 are not needed going backward)
+    // LDS image of the trunk block from w2 on (w1/b1 are not needed going backward), or all of it when fused
     float* Wimg = smem;
-    const float* W = Wimg - tr.w2;                 // so that W + tr.<off> addresses the block as usual
-    const int wfl = tr.size - tr.w2;
+    const int w_first = FUSED ? 0 : tr.w2;
+    const float* W = Wimg - w_first;               // so that W + tr.<off> addresses the block as usual
+    const int wfl = tr.size - w_first;
     float* X = Wimg + a.wbuf_floats;
     float* H1 = X + R * ldO;
     float* H2 = H1 + R * ldH;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     SG_PPO_WALL(6);
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
-    sg_stage_issue<12>(wv, a.params + tr.off + tr.w2, wfl / 4);
+    sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
     constexpr int UX = MT <= 2 ? 4 : 8;          // float4 per thread for an [R][ld <= 116] tile at 256 threads
     constexpr int UO = MT <= 2 ? 2 : 4;          // ... for an [R][ldP <= 64] tile
     const int ta = critic ? t : 0;
@@ -202,10 +206,12 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     const float* gO1 = a.OUT[two_heads ? 1 : ta] + (size_t)row0 * ldP;
     float4 xv[UX], h1v[UX], h2v[UX], o0v[UO], o1v[UO];
     sg_stage_issue<UX>(xv, gX, R * ldO / 4);
-    sg_stage_issue<UX>(h1v, gH1, R * ldH / 4);
-    sg_stage_issue<UX>(h2v, gH2, R * ldH / 4);
-    sg_stage_issue<UO>(o0v, gO0, R * ldP / 4);
-    if (two_heads) sg_stage_issue<UO>(o1v, gO1, R * ldP / 4);
+    if (!FUSED) {
+        sg_stage_issue<UX>(h1v, gH1, R * ldH / 4);
+        sg_stage_issue<UX>(h2v, gH2, R * ldH / 4);
+        sg_stage_issue<UO>(o0v, gO0, R * ldP / 4);
+        if (two_heads) sg_stage_issue<UO>(o1v, gO1, R * ldP / 4);
+    }
     float actv[2] = {0.f, 0.f}, scv[4] = {0.f, 0.f, 0.f, 0.f};
     if (!critic) {
 #pragma unroll
@@ -217,10 +223,12 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
         for (int q = 0; q < 4; ++q) scv[q] = a.SC[(size_t)q * a.sc_stride + row0 + r];
     }
     sg_stage_commit<UX>(X, xv, gX, R * ldO / 4);
-    sg_stage_commit<UX>(H1, h1v, gH1, R * ldH / 4);
-    sg_stage_commit<UX>(H2, h2v, gH2, R * ldH / 4);
-    sg_stage_commit<UO>(O0, o0v, gO0, R * ldP / 4);
-    if (two_heads) sg_stage_commit<UO>(O1, o1v, gO1, R * ldP / 4);
+    if (!FUSED) {
+        sg_stage_commit<UX>(H1, h1v, gH1, R * ldH / 4);
+        sg_stage_commit<UX>(H2, h2v, gH2, R * ldH / 4);
+        sg_stage_commit<UO>(O0, o0v, gO0, R * ldP / 4);
+        if (two_heads) sg_stage_commit<UO>(O1, o1v, gO1, R * ldP / 4);
+    }
     if (!critic) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int i = tid + u * 256; if (i < R * A) ACT[i] = actv[u]; }
@@ -231,8 +239,19 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
-    sg_stage_commit<12>(Wimg, wv, a.params + tr.off + tr.w2, wfl / 4);
+    sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
     __syncthreads();
+    if (FUSED) {   // forward on this row group (a2c/model.py:255-264, a2c/distributions.py:109-118), activations stay in LDS
+        const float* b1 = W + tr.b1;
+        const float* b2 = W + tr.b2;
+        const float* bh = W + tr.bh;
+        sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        __syncthreads();
+        sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        __syncthreads();
+        sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
+        __syncthreads();
+    }
     SG_PPO_STAMP(9);
 
     // ---- loss and d(loss)/d(head outputs)  (a2c/algo/ppo.py:92-106)

@@ -150,6 +150,17 @@ def test_ppo_update_golden(sg, name):
     assert_close(p.get_flat_params(), g["params1"], what="params after update")
 
 
+def test_ppo_mlp_separate_forward_kernel_matches_golden(sg, monkeypatch):
+    """Policy normally runs the fused forward+backward kernel; the two-kernel path (what SplitPolicy uses) must give
+    the same trajectory on it."""
+    monkeypatch.setenv("SG_PPO_FUSED", "0")
+    g = load("ppo_mlp_northstar")
+    p, agent, ro = _ppo_problem(sg, g)
+    losses = agent.update(ro, perms=g["perms"])
+    assert_close(losses, g["losses"], what="ppo losses")
+    assert_close(p.get_flat_params(), g["params1"], what="params after update")
+
+
 def test_ppo_graph_replay_is_bit_exact(sg, monkeypatch):
     """Two updates through the captured hipGraph equal two updates launched kernel by kernel."""
     g = load("ppo_mlp_northstar")
