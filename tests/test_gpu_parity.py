@@ -161,6 +161,39 @@ def test_ppo_mlp_separate_forward_kernel_matches_golden(sg, monkeypatch):
     assert_close(p.get_flat_params(), g["params1"], what="params after update")
 
 
+@pytest.mark.parametrize("kind,O,A,H,f,T,N,M,E", [("mlp", 47, 12, 64, 1, 5, 7, 3, 2), ("mlp", 11, 3, 64, 1, 9, 13, 4, 2), ("mlp", 5, 2, 8, 1, 3, 1, 1, 3),
+                                                   ("split", 14, 7, 100, 1, 7, 9, 5, 2), ("split", 64, 28, 100, 4, 3, 11, 2, 1)])
+def test_ppo_ragged_minibatches_vs_oracle(sg, kind, O, A, H, f, T, N, M, E):
+    """T*N not divisible by num_mini_batch (the sampler drops the remainder) and minibatches that are not a multiple of
+    the 16-row groups: fused (Policy) and two-kernel (SplitPolicy) paths against the CPU oracle, two updates."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(O * 100 + T)
+    bk = {"recurrent": False, "hidden_size": H} if kind == "mlp" else {"hidden_size": H, "num_feet": f}
+    pol = (sg.Policy if kind == "mlp" else sg.SplitPolicy)((O,), Box((A,)), base_kwargs=bk, seed=T)
+    ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, 1)
+    obs = rng.standard_normal((T + 1, N, O)).astype(np.float32)
+    ro.obs.copy_(ro.obs.new_tensor(obs))
+    v, a, lp, _ = pol.act(obs[:-1].reshape(-1, O), None, None, noise=rng.standard_normal((T * N, A)).astype(np.float32))
+    npv = lambda x: x.numpy() if hasattr(x, "numpy") else np.asarray(x)  # noqa: E731
+    act, logp = npv(a).reshape(T, N, A), npv(lp).reshape(T, N, 1)
+    vp = np.concatenate([npv(v).reshape(T, N, 1), np.zeros((1, N, 1), np.float32)])
+    ret = (vp + rng.standard_normal(vp.shape) * 0.5).astype(np.float32)
+    ro.actions.copy_(ro.actions.new_tensor(act)); ro.action_log_probs.copy_(ro.action_log_probs.new_tensor(logp))
+    ro.value_preds.copy_(ro.value_preds.new_tensor(vp)); ro.returns.copy_(ro.returns.new_tensor(ret))
+    p0 = (pol.get_flat_params() + 0.02 * rng.standard_normal(pol.num_params)).astype(np.float32)   # leave ratio == 1
+    pol.set_flat_params(p0)
+    agent = sg.algo.PPO(pol, 0.2, E, M, 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    cfg = orc.ppo_cfg(0.2, E, M, 0.5, 0.01, 3e-4, 1e-5, 0.5, True)
+    for _ in range(2):
+        perms = np.stack([rng.permutation(T * N) for _ in range(E)]).astype(np.int64)
+        losses = agent.update(ro, perms=perms)
+        olosses = orc.ppo_update(d, par, adam, cfg, obs, act, vp[..., 0], ret[..., 0], logp[..., 0], perms)
+        assert_close(losses, olosses, what="PPO losses")
+        assert_close(pol.get_flat_params(), par, what="policy params")
+
+
 def test_ppo_graph_replay_is_bit_exact(sg, monkeypatch):
     """Two updates through the captured hipGraph equal two updates launched kernel by kernel."""
     g = load("ppo_mlp_northstar")
@@ -296,6 +329,35 @@ def test_disc_resume_and_graph_replay_are_bit_exact(sg, name, monkeypatch):
     Cd.update_gail_dyn(loader, ro, **kw0)
     lc = Cd.update_gail_dyn(loader, ro, **kw1)
     assert lc == la and np.array_equal(Cd.get_flat_params(), A.get_flat_params())
+
+
+@pytest.mark.parametrize("chain", ["thin", "wide"])
+@pytest.mark.parametrize("F,Hd,B,Ne,T,N", [(7, 16, 1, 5, 3, 2), (7, 16, 3, 11, 4, 5), (7, 16, 10, 35, 6, 7), (25, 100, 17, 60, 5, 11),
+                                          (86, 100, 33, 70, 3, 40), (86, 100, 130, 300, 9, 30)])
+def test_disc_ragged_batches_vs_oracle(sg, chain, F, Hd, B, Ne, T, N, monkeypatch):
+    """Batch sizes that are not multiples of the 4-row / 16-row blocks, expert sets that do not divide into batches
+    (drop_last), rollouts that do not either: both chain kernels against the CPU oracle."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("SG_DISC_CHAIN", chain)
+    rng = np.random.default_rng(F * 1000 + B)
+    D = sg.algo.gail.Discriminator(F, Hd, None, seed=B)
+    p0 = D.get_flat_params()
+    ro = sg.RolloutStorage(T, N, (3,), Box((2,)), 1, F)
+    feat = rng.standard_normal((T + 1, N, F)).astype(np.float32)
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(feat))
+    expert = (rng.standard_normal((Ne, F)) * 0.7 + 0.2).astype(np.float32)
+    n_d = min(Ne // B, (T * N) // B)
+    eperm = rng.permutation(Ne).astype(np.int64)
+    pperm = rng.permutation(T * N).astype(np.int64)
+    alpha = rng.random(n_d * B).astype(np.float32)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    for _ in range(2):   # two epochs: the second one continues the Adam state (and replays the captured graph)
+        losses = D.update_gail_dyn(Loader(expert, B), ro, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+        assert D.last_n_steps == n_d
+        olosses, on = orc.disc_update(F, Hd, par, adam, expert, feat, B, eperm, pperm, alpha)
+        assert on == n_d
+        assert_close(losses, olosses, what=f"D losses B={B}")
+        assert_close(D.get_flat_params(), par, what=f"D params B={B}")
 
 
 def test_disc_short_expert_is_an_error(sg):
