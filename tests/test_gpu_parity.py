@@ -390,6 +390,24 @@ def test_checkpoint_interop_policy(sg, name, tmp_path):
     assert np.array_equal(np.concatenate([x.reshape(-1) for x in back["state_dict"].values()]), g["flat"])
 
 
+def test_policy_ensemble_batched_inference(sg):
+    """N rows, each drawing one of K policies (hopper_env_combined_policy.py:211-216): the grouped batched forwards
+    equal row-by-row batch-1 `act` calls with the same sampling noise."""
+    from simgan_amd.ensemble import PolicyEnsemble
+    rng = np.random.default_rng(5)
+    pols = [sg.SplitPolicy((14,), Box((7,)), base_kwargs={"hidden_size": 100, "num_feet": 1}, seed=70 + k) for k in range(5)]
+    ens = PolicyEnsemble(pols)
+    obs = rng.standard_normal((37, 14)).astype(np.float32)
+    noise = rng.standard_normal((37, 7)).astype(np.float32)
+    act, ind = ens.act(obs, noise=noise, rng=np.random.default_rng(9))
+    assert act.shape == (37, 7) and set(np.unique(ind)) <= set(range(5)) and len(np.unique(ind)) > 1
+    for r in range(37):
+        _, a1, _, _ = pols[ind[r]].act(obs[r:r + 1], None, None, noise=noise[r:r + 1])
+        assert_close(act[r], np.asarray(a1)[0], rtol=1e-6, what=f"row {r}")
+    det, _ = ens.act(obs, ind=ind, deterministic=True)
+    assert not np.allclose(det, act)
+
+
 def test_checkpoint_interop_discriminator(sg):
     import os
 
