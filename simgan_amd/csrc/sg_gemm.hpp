@@ -59,7 +59,7 @@ __device__ __forceinline__ float sg_tanh(float x) {
     const float x2 = x * x;
     const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
     const float t = __expf(2.f * x);
-    const float big = 1.f - 2.f * __frcp_rn(t + 1.f);
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);   // v_rcp_f32 (1 ulp), not the IEEE division sequence
     return fabsf(x) < 0.1f ? poly : big;
 }
 
