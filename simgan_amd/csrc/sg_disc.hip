@@ -403,6 +403,10 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
     const int n_vec = (3 * dd.Hp + 4 + 63) / 64;
+    const int th_ = dd.Hp / 16, tf_ = dd.Fp / 16;
+    const char* xenv = getenv("SG_WGRAD_XCD");
+    wa.xcd_map = (th_ <= 7 && n_vec <= (8 - th_) * (th_ + tf_) && !(xenv && !strcmp(xenv, "0"))) ? 1 : 0;
+    const int n_wgrad_blocks = wa.xcd_map ? ((2 * G + 7) & ~7) + 8 * (th_ + tf_) : n_tiles + n_vec + 2 * G;
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
     // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit
@@ -441,7 +445,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             wa.next = pg;
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
             else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
-            SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_tiles + n_vec + 2 * G), dim3(SG_WGRAD_THREADS), 0, wa);
+            SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa);
             if (sharded) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
                 hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,

@@ -687,6 +687,7 @@ struct WgradArgs {
     int k1;                   // 1-based step index within the epoch: Adam step t = st->t0 + k1, scalars in slot t & 1
     float* wT;                // k_disc_chain4's weight images to keep in step (NULL: not maintained)
     long long* dbg;           // optional wall-clock stamps per block (test hook), NULL in production
+    int xcd_map;              // tiles grouped by row panel per XCD (grid = align8(2G) + 8 * (th + tf) blocks)
 };
 
 // torch.optim.Adam single-tensor math (a2c/algo/gail.py:48,186-188: lr 1e-3, eps 1e-8)
@@ -721,7 +722,23 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
         return;
     }
-    const int b = blockIdx.x - 2 * a.G;
+    int b = blockIdx.x - 2 * a.G;
+    if (a.xcd_map) {
+        // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2.  All tiles of one row
+        // panel (same 16 rows of W2 / W1, hence the same left slab) are given to one XCD, so an XCD pulls one
+        // left slab plus the right slabs from the memory side instead of nearly all of both stacks; the spare XCD
+        // column(s) take the vector blocks.
+        const int base = (2 * a.G + 7) & ~7;
+        const int lb = (int)blockIdx.x - base;
+        if (lb < 0) return;
+        const int xcd = lb & 7, slot = lb >> 3;
+        if (xcd < th) b = slot < th ? xcd * th + slot : T2 + xcd * tf + (slot - th);
+        else {
+            const int vid = (xcd - th) * (th + tf) + slot;
+            if (vid >= (3 * d.Hp + 4 + 63) / 64) return;
+            b = T2 + T1 + vid;
+        }
+    }
     if (b < T2 + T1) {
         const bool w2 = b < T2;
         const int t = w2 ? b : b - T2;

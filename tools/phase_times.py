@@ -44,8 +44,9 @@ G = (w["B"] + 15) // 16
 kf, kh = (w["F"] + 15) // 16, (w["Hd"] + 15) // 16
 nt, nv = kh * kh + kh * kf, (3 * 16 * kh + 4 + 63) // 64
 st = wg[:, 0]
-print(f"wgrad: all blocks start {10 * (st[:2 * G + nt + nv].min() - t0)}..{10 * (st[:2 * G + nt + nv].max() - t0)} ns after the chain's first block")
-tl = wg[2 * G:2 * G + nt]
+live = st[st > 0]
+print(f"wgrad: all blocks start {10 * (live.min() - t0)}..{10 * (live.max() - t0)} ns after the chain's first block")
+tl = wg[wg[:, 1] > 0]     # tile blocks are the ones that stamp their load / reduce / store points
 for nm, k in (("operands loaded + MFMA", 1), ("LDS reduce barrier", 2), ("Adam + stores issued", 3)):
     dt = 10 * (tl[:, k] - tl[:, 0])
     print(f"wgrad tiles: {nm:24s} at +{dt.min()}..{dt.max()} ns (median {int(np.median(dt))})")
