@@ -592,8 +592,16 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             GX[s * ldAF + col] = gown;
         }
         SG_PHASE_SYNC(11);
-        {   // per-row |g|, penalty coefficient (a2c/algo/gail.py:88), then bd1 = (c_r g) W1^T; every wave
-            // recomputes the four norms from LDS instead of spending a barrier on them
+        {   // per-row |g|, penalty coefficient c_r (a2c/algo/gail.py:88) and bd1 = (c_r g) W1^T.  The row scale
+            // commutes with the GEMM, so g W1^T is issued straight after the barrier and scaled by this lane's own
+            // c_r in the epilogue; the norms (every wave recomputes the four of them from LDS rather than spending a
+            // barrier) overlap the MFMAs instead of preceding them.
+            float4 av[1][SG4_NCH(Fp)];
+            float o[1] = {0.f};
+            if (actH) {
+                sg4_load_a<Fp, 1>(av, GX, ldAF, lane);
+                sg4_mma<Fp, 1>(av, w1, lane, o);
+            }
             float ss = 0.f;
 #pragma unroll
             for (int q = 0; q < KF; ++q) { const float v = GX[s * ldAF + 16 * q + cl]; ss += v * v; }
@@ -606,15 +614,8 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
                 const float rl = sg4_colsum(valid ? (nn - 1.f) * (nn - 1.f) : 0.f);
                 if (lane < 4) part[3 * Hp + lane] = lane == 3 ? rl : 0.f;         // sum (|g|-1)^2
             }
-            const float cri = __shfl(cr, 16 * (lane & 3));                         // coefficient of this lane's A row
             if (actH) {
-                float4 av[1][SG4_NCH(Fp)];
-                float o[1];
-                sg4_load_a<Fp, 1>(av, GX, ldAF, lane);
-#pragma unroll
-                for (int tc = 0; tc < SG4_NCH(Fp); ++tc) { av[0][tc].x *= cri; av[0][tc].y *= cri; av[0][tc].z *= cri; av[0][tc].w *= cri; }
-                sg4_mma<Fp, 1>(av, w1, lane, o);
-                const float bd1 = o[0];
+                const float bd1 = o[0] * cr;
                 const float bu1 = bd1 * (1.f - h1 * h1);
                 BU1[s * ldAH + col] = bu1;
                 R2s[SG_STK(Kt, rowA + s, col)] = bu1;
