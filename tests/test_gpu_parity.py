@@ -360,6 +360,32 @@ def test_disc_ragged_batches_vs_oracle(sg, chain, F, Hd, B, Ne, T, N, monkeypatc
         assert_close(D.get_flat_params(), par, what=f"D params B={B}")
 
 
+@pytest.mark.parametrize("chain", ["thin", "wide"])
+def test_disc_saturated_activations_vs_oracle(sg, chain, monkeypatch):
+    """Weights x4 and inputs x3: tanh units saturate, logits reach +-20 (sigmoid / log-sigmoid tails), some
+    gradient-penalty rows have |g| far from 1 -- the step must still track the CPU oracle."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("SG_DISC_CHAIN", chain)
+    F, Hd, B, Ne, T, N = 86, 100, 128, 512, 8, 64
+    rng = np.random.default_rng(17)
+    D = sg.algo.gail.Discriminator(F, Hd, None, seed=2)
+    p0 = (D.get_flat_params() * 4.0).astype(np.float32)
+    D.set_flat_params(p0)
+    ro = sg.RolloutStorage(T, N, (3,), Box((2,)), 1, F)
+    feat = (3.0 * rng.standard_normal((T + 1, N, F))).astype(np.float32)
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(feat))
+    expert = (3.0 * rng.standard_normal((Ne, F)) + 1.0).astype(np.float32)
+    eperm, pperm = rng.permutation(Ne).astype(np.int64), rng.permutation(T * N).astype(np.int64)
+    alpha = rng.random(4 * B).astype(np.float32)
+    losses = D.update_gail_dyn(Loader(expert, B), ro, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    olosses, n_d = orc.disc_update(F, Hd, par, adam, expert, feat, B, eperm, pperm, alpha)
+    assert n_d == 4 and D.last_n_steps == 4
+    assert all(np.isfinite(x) for x in losses) and olosses[0] > 5.0      # the penalty term dominates: far from the init regime
+    assert_close(losses, olosses, what="saturated D losses")
+    assert_close(D.get_flat_params(), par, what="saturated D params")
+
+
 def test_disc_short_expert_is_an_error(sg):
     """Ne < batch: the reference raises on the alpha*expert + (1-alpha)*policy size mismatch."""
     D = sg.algo.gail.Discriminator(7, 16, None)
