@@ -62,7 +62,7 @@ static bool disc_chain_thin(const SgDiscDesc& dd) {
 }
 static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, const DiscArgs& a) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
-    const dim3 block(512);
+    const dim3 block(64 * (kf > kh ? kf : kh));   // one wave per 16 output columns: no idle wave to launch and drain
 #define SG_CHAIN4(KF_, KH_)                                                                                         \
     SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<KF_, KH_>), grid, block, 0, a.params, a.wT, a.ops, a.part, a.dbg, \
               a.B, a.G, a.inv_B, a.lambda_)
