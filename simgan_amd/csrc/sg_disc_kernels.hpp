@@ -460,11 +460,11 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         // loads are unconditional and in consumption order (idle waves fetch a duplicate slice): memory
         // returns in order, so the first GEMM waits for its own operands only and the later matrices land
         // while it runs.  The scheduling barriers keep the compiler from sinking the small loads to the end.
-        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
-        const float b3 = P[o_b3];
-        __builtin_amdgcn_sched_barrier(0);
         sg4_load_a<Fp, 1>(ax, R1s + (size_t)r0 * ldF, ldF, lane);   // pre-gathered by the previous launch
         sg4_load_w<Fp>(w1, I_W1, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];   // first needed by the first epilogue
+        const float b3 = P[o_b3];
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // every wave's W1 request is queued before anyone's W2: the first GEMM starts ~2k cycles earlier
         __builtin_amdgcn_sched_barrier(0);
@@ -539,10 +539,10 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         float* GX = sm + 5 * 4 * ldAH;   // [4][ldAF]
         float4 w1t[SG4_NW(Hp)];
         float4 ax[1][SG4_NCH(Fp)];
-        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
-        __builtin_amdgcn_sched_barrier(0);
         sg4_load_a<Fp, 1>(ax, R1s + (size_t)rowB * ldF, ldF, lane);      // pre-gathered mixup rows
         sg4_load_w<Fp>(w1, I_W1, wvH, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // see the BCE branch
         __builtin_amdgcn_sched_barrier(0);
