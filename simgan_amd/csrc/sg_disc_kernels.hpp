@@ -466,7 +466,6 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];   // first needed by the first epilogue
         const float b3 = P[o_b3];
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();   // every wave's W1 request is queued before anyone's W2: the first GEMM starts ~2k cycles earlier
         __builtin_amdgcn_sched_barrier(0);
         sg4_load_w<Hp>(w2, I_W2, wvH, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -544,7 +543,6 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         __builtin_amdgcn_sched_barrier(0);
         b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();   // see the BCE branch
         __builtin_amdgcn_sched_barrier(0);
         sg4_load_w<Hp>(w2, I_W2, wvH, lane);
         __builtin_amdgcn_sched_barrier(0);
