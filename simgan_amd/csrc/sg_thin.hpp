@@ -32,8 +32,8 @@ __device__ __forceinline__ f32x4 sg4_mfma(float a, float b, f32x4 c) {
 // contiguous KiB (8 cache lines) instead of 64 scattered 16-byte pieces.  For y = x W^T the image is
 // built from W, for y = d W from W^T; k_disc_wgrad writes both images next to the canonical layout.
 __host__ __device__ __forceinline__ int sg4_img_index(int n, int k, int K) {
-    const int KS = K / 4, s = k / KS, ko = k - s * KS;
-    return ((((n >> 4) * (K / 16) + (ko >> 2)) * 64 + 16 * s + (n & 15)) << 2) + (ko & 3);
+    const int KS = K >> 2, s = (k >= KS) + (k >= 2 * KS) + (k >= 3 * KS), ko = k - s * KS;   // s = k / KS without a division
+    return ((((n >> 4) * (K >> 4) + (ko >> 2)) * 64 + 16 * s + (n & 15)) << 2) + (ko & 3);
 }
 
 // This lane's B operand for the whole kernel: wave-th 16-column slice of an image.
