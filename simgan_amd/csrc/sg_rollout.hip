@@ -133,33 +133,43 @@ extern "C" int sg_rollout_after_update(sg_rollout* r) {
 }
 
 // One thread per environment column; reverse scan over T (a2c/storage.py:109-142).
+// The recurrence is serial in t, but its inputs are not: each chunk of 8 time steps is fetched with 32 independent
+// loads before the 8 dependent updates, so a column pays one memory round trip per chunk instead of one per step.
 __global__ void k_compute_returns(int T, int N, const float* __restrict__ rewards, float* value_preds,
                                   float* returns, const float* __restrict__ masks,
                                   const float* __restrict__ bad_masks, const float* __restrict__ next_value,
                                   int use_gae, float gamma, float lam, int proper) {
+    constexpr int C = 8;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    if (use_gae) {
-        value_preds[(size_t)T * N + n] = next_value[n];
-        float gae = 0.f;
-        float v_next = next_value[n];
-        for (int t = T - 1; t >= 0; --t) {
+    const float nv = next_value[n];
+    float gae = 0.f, v_next = nv, ret = nv;
+    if (use_gae) value_preds[(size_t)T * N + n] = nv;
+    else returns[(size_t)T * N + n] = nv;
+    for (int t1 = T - 1; t1 >= 0; t1 -= C) {
+        float rw[C], vp[C], mk[C], bm[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int t = t1 - u >= 0 ? t1 - u : 0;
             const size_t i = (size_t)t * N + n, j = i + N;
-            const float v = value_preds[i], m = masks[j];
-            const float delta = rewards[i] + gamma * v_next * m - v;
-            gae = delta + gamma * lam * m * gae;
-            if (proper) gae = gae * bad_masks[j];
-            returns[i] = gae + v;
-            v_next = v;
+            rw[u] = rewards[i]; vp[u] = value_preds[i]; mk[u] = masks[j]; bm[u] = bad_masks[j];
         }
-    } else {
-        float ret = next_value[n];
-        returns[(size_t)T * N + n] = ret;
-        for (int t = T - 1; t >= 0; --t) {
-            const size_t i = (size_t)t * N + n, j = i + N;
-            if (proper) ret = (ret * gamma * masks[j] + rewards[i]) * bad_masks[j] + (1.f - bad_masks[j]) * value_preds[i];
-            else ret = ret * gamma * masks[j] + rewards[i];
-            returns[i] = ret;
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int t = t1 - u;
+            if (t < 0) break;
+            const size_t i = (size_t)t * N + n;
+            if (use_gae) {
+                const float delta = rw[u] + gamma * v_next * mk[u] - vp[u];
+                gae = delta + gamma * lam * mk[u] * gae;
+                if (proper) gae = gae * bm[u];
+                returns[i] = gae + vp[u];
+                v_next = vp[u];
+            } else {
+                if (proper) ret = (ret * gamma * mk[u] + rw[u]) * bm[u] + (1.f - bm[u]) * vp[u];
+                else ret = ret * gamma * mk[u] + rw[u];
+                returns[i] = ret;
+            }
         }
     }
 }
