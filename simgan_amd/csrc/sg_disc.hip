@@ -139,13 +139,25 @@ __global__ void k_returns_step(float* returns, const float* reward, const float*
 // Per-column scan over T of the same recurrence; keeps every step's returns for the statistics.
 __global__ void k_returns_scan(float* d_returns, const float* raw /*[T,N]*/, const float* masks /*[T+1,N]*/,
                                float gamma, int first, int T, int N, float* rets /*[T,N]*/) {
+    constexpr int C = 8;   // steps fetched with independent loads before their (serial) updates
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float ret = first ? 0.f : d_returns[n];
-    for (int t = 0; t < T; ++t) {
-        const float r = raw[(size_t)t * N + n];
-        ret = (first && t == 0) ? r : ret * gamma * masks[(size_t)t * N + n] + r;
-        rets[(size_t)t * N + n] = ret;
+    for (int t0 = 0; t0 < T; t0 += C) {
+        float rw[C], mk[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int t = t0 + u < T ? t0 + u : T - 1;
+            rw[u] = raw[(size_t)t * N + n];
+            mk[u] = masks[(size_t)t * N + n];
+        }
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int t = t0 + u;
+            if (t >= T) break;
+            ret = (first && t == 0) ? rw[u] : ret * gamma * mk[u] + rw[u];
+            rets[(size_t)t * N + n] = ret;
+        }
     }
     d_returns[n] = ret;
 }
@@ -169,19 +181,28 @@ __global__ __launch_bounds__(256) void k_batch_stats(const float* rets, int N, d
 }
 
 // Sequential Chan merge over t (float64 state) -> per-step scale = sqrt(var_t + 1e-7)
-__global__ void k_rms_scan(const double* stats, int T, double n_global, double* rms /*[3] in/out*/, float* scale /*[T]*/) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double mean = rms[0], var = rms[1], count = rms[2];
-    for (int t = 0; t < T; ++t) {
-        const double bmean = (double)(float)(stats[t] / n_global);
-        const double bvar = (double)(float)(stats[T + t] / n_global);
-        const double delta = bmean - mean, tot = count + n_global;
-        const double new_mean = mean + delta * n_global / tot;
-        const double M2 = var * count + bvar * n_global + delta * delta * count * n_global / tot;
-        mean = new_mean; var = M2 / tot; count = tot;
-        scale[t] = (float)sqrt(var + 1e-7);
+// RunningMeanStd.update over the T batches in order (float64 Chan merge, running_mean_std.py:27-58): serial, so one
+// lane runs it -- from LDS, where the whole block first put the 2T batch statistics with parallel loads.
+__global__ __launch_bounds__(256) void k_rms_scan(const double* stats, int T, double n_global, double* rms /*[3] in/out*/,
+                                                  float* scale /*[T]*/) {
+    extern __shared__ __attribute__((aligned(16))) double sst[];   // [2T] statistics, then [T] scales
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) sst[i] = stats[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mean = rms[0], var = rms[1], count = rms[2];
+        for (int t = 0; t < T; ++t) {
+            const double bmean = (double)(float)(sst[t] / n_global);
+            const double bvar = (double)(float)(sst[T + t] / n_global);
+            const double delta = bmean - mean, tot = count + n_global;
+            const double new_mean = mean + delta * n_global / tot;
+            const double M2 = var * count + bvar * n_global + delta * delta * count * n_global / tot;
+            mean = new_mean; var = M2 / tot; count = tot;
+            sst[2 * T + t] = sqrt(var + 1e-7);
+        }
+        rms[0] = mean; rms[1] = var; rms[2] = count;
     }
-    rms[0] = mean; rms[1] = var; rms[2] = count;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) scale[t] = (float)sst[2 * T + t];
 }
 
 __global__ void k_normalize_rewards(float* rewards, const float* scale, int T, int N) {
@@ -616,7 +637,7 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats, T));            // per-step sums over all ranks
     hipLaunchKernelGGL(k_batch_stats, dim3(T), dim3(256), 0, ctx->stream, rets, N, n_global, stats, 1);
     if (ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(ctx, stats + T, T));        // squares about the global mean
-    hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(1), 0, ctx->stream, stats, T, n_global, rms, scale);
+    hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(256), sizeof(double) * 3 * T, ctx->stream, stats, T, n_global, rms, scale);
     hipLaunchKernelGGL(k_normalize_rewards, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, ctx->stream, rewards, scale, T, N);
     SG_CHECK(hipGetLastError());
     SG_TRY(sg_ctx_fetch_f64(ctx, rms, rms_state, 3));
