@@ -110,9 +110,24 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
     sg_stage(W, a.params, d.total / 4);
     for (int base = blockIdx.x * R; base < a.n; base += gridDim.x * R) {
         __syncthreads();
-        for (int i = tid; i < R * Fp; i += blockDim.x) {
-            const int r = i / Fp, c = i - r * Fp;
-            X[r * ldF + c] = (base + r < a.n && c < d.F) ? a.x[(size_t)(base + r) * d.F + c] : 0.f;
+        {   // the row tile through range-checked buffer loads, all requests of a thread in flight together: rows past
+            // n and the padding columns [F, Fp) read as zero without a guard the compiler would turn into a branch
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)base * d.F, 0, (a.n - base < R ? a.n - base : R) * d.F * 4, 0x00020000);
+            for (int i0 = tid; i0 < R * Fp; i0 += 12 * blockDim.x) {
+                float v[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * blockDim.x, r = i / Fp, c = i - r * Fp;
+                    const int off = (i < R * Fp && c < d.F) ? (r * d.F + c) * 4 : 0x7ffffff0;
+                    v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * blockDim.x, r = i / Fp, c = i - r * Fp;
+                    if (i < R * Fp) X[r * ldF + c] = v[u];
+                }
+            }
         }
         __syncthreads();
         sg_layer_nt<2>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });

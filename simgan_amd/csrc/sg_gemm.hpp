@@ -389,18 +389,20 @@ __device__ __forceinline__ void sg_colsum(const float* M, int ldm, int R, int Np
 
 // Linear copy global -> LDS, 16 bytes per lane (n4 = number of float4), 8 loads in flight per
 // lane per round (all rounds when n4 is a compile-time constant and the loop unrolls).
+typedef unsigned int sg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sg_buffer_load4(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    const sg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0);
+    return float4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+}
 __device__ __forceinline__ void sg_stage(float* lds, const float* __restrict__ g, int n4) {
-    const float4* src = reinterpret_cast<const float4*>(g);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, n4 * 16, 0x00020000);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int nt = blockDim.x;
 #pragma unroll 2
     for (int base = threadIdx.x; base < n4; base += 8 * nt) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * nt;
-            v[u] = i < n4 ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int u = 0; u < 8; ++u) v[u] = sg_buffer_load4(rsrc, (base + u * nt) * 16);   // range-checked: zeros past n4
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + u * nt;
@@ -416,11 +418,6 @@ __device__ __forceinline__ void sg_stage(float* lds, const float* __restrict__ g
 // The loads are buffer loads: the hardware range-checks every lane against the n4*16-byte extent and returns
 // zeros beyond it, so there is no per-load guard for the compiler to turn into a branch (which would make
 // each request wait for the previous one).
-typedef unsigned int sg_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 sg_buffer_load4(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
-    const sg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0);
-    return float4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
-}
 template <int U>
 __device__ __forceinline__ void sg_stage_issue(float4 (&v)[U], const float* __restrict__ g, int n4) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, n4 * 16, 0x00020000);
