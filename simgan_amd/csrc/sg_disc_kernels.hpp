@@ -399,7 +399,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // k_disc_chain4<KF,KH>: the same serial part of the step on 4-row blocks (sg_thin.hpp).
-//   grid 12*G workgroups of 512 threads.  Workgroups [0,4G): 4 mixup rows (batch rows 4q..4q+3) through
+//   grid 12*G workgroups of max(KF,KH) waves (one per 16 output columns).  Workgroups [0,4G): 4 mixup rows (batch rows 4q..4q+3) through
 //   the 7 dependent GEMMs of the gradient penalty; workgroups [4G,12G): the matching 4 expert rows (even)
 //   or 4 policy rows (odd) through forward / BCE / backward-to-activations.  Wave w owns hidden (or
 //   input) columns [16w, 16w+16) in every phase and holds its slice of W1, W2, W1^T and W2^T in
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 //   already run; LDS carries only the 4-row activations between phases.  Compared with
 //   k_disc_chain the step uses 4x the CUs and a phase costs 28 MFMA issues per wave instead of 56
 //   16x16x4 issues (4x the cycles each).  Operand stacks, partials and math are identical.
-//   Requires compile-time KF, KH <= 8 (one wave per 16 columns, 8 waves).
+//   Requires compile-time KF, KH <= 8 (one wave per 16 columns, at most 8 waves; launched with exactly max(KF,KH) waves).
 // Arguments are individual scalars / pointers (14 dwords), not a struct: the code object asks the command
 // processor to preload them into SGPRs (-amdgpu-kernarg-preload-count), so the first global loads do not wait
 // for a kernarg fetch from memory (~1 us after a fresh launch).
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         float* DZ2 = H1 + 4 * ldAH;     // [4][ldAH]
         float* LP = DZ2 + 4 * ldAH;     // [8 waves][4 rows] logit partials
         float4 ax[1][SG4_NCH(Fp)];
-        // loads are unconditional and in consumption order (idle waves fetch a duplicate slice): memory
+        // loads are unconditional and in consumption order (a wave past KH, if the block has one, fetches a duplicate slice): memory
         // returns in order, so the first GEMM waits for its own operands only and the later matrices land
         // while it runs.  The scheduling barriers keep the compiler from sinking the small loads to the end.
         sg4_load_a<Fp, 1>(ax, R1s + (size_t)r0 * ldF, ldF, lane);   // pre-gathered by the previous launch
