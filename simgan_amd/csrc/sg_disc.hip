@@ -442,7 +442,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int th_ = dd.Hp / 16, tf_ = dd.Fp / 16;
     const char* xenv = getenv("SG_WGRAD_XCD");
     wa.xcd_map = (th_ <= 7 && n_vec <= (8 - th_) * (th_ + tf_) && !(xenv && !strcmp(xenv, "0"))) ? 1 : 0;
-    const int n_wgrad_blocks = wa.xcd_map ? ((2 * G + 7) & ~7) + 8 * (th_ + tf_) : n_tiles + n_vec + 2 * G;
+    const int n_wgrad_blocks = wa.xcd_map ? 8 * (th_ + tf_) + 2 * G : n_tiles + n_vec + 2 * G;
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
     // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit

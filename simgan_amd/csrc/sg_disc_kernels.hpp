@@ -714,29 +714,37 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
     // test hook: wall clock (100 MHz) at block start / after the operand loads / after the LDS reduce / end
     long long* stamp = (a.dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
     if (stamp) stamp[0] = wall_clock64();
-    // the first 2G blocks prepare the next step (two dependent global round trips: index, then row): they are
-    // dispatched first so they finish with the tiles; one lane also evaluates the next step's Adam scalars
-    if ((int)blockIdx.x < 2 * a.G) {
-        if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
-        if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
-        return;
-    }
-    int b = blockIdx.x - 2 * a.G;
+    int b;
     if (a.xcd_map) {
         // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2.  All tiles of one row
         // panel (same 16 rows of W2 / W1, hence the same left slab) are given to one XCD, so an XCD pulls one
         // left slab plus the right slabs from the memory side instead of nearly all of both stacks; the spare XCD
-        // column(s) take the vector blocks.
-        const int base = (2 * a.G + 7) & ~7;
-        const int lb = (int)blockIdx.x - base;
-        if (lb < 0) return;
-        const int xcd = lb & 7, slot = lb >> 3;
+        // column(s) take the vector blocks and, in the first slot left over, the lane that evaluates the next
+        // step's Adam scalars.  The 2G blocks that copy the next step's rows come last: they are short.
+        const int ntv = 8 * (th + tf), NV = (3 * d.Hp + 4 + 63) / 64;
+        const bool has_spare = (8 - th) * (th + tf) > NV;
+        if ((int)blockIdx.x >= ntv) {
+            const int j = blockIdx.x - ntv;
+            if (!has_spare && j == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
+            if (a.next.ops) sg_disc_pregather(a.next, j);
+            return;
+        }
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         if (xcd < th) b = slot < th ? xcd * th + slot : T2 + xcd * tf + (slot - th);
         else {
             const int vid = (xcd - th) * (th + tf) + slot;
-            if (vid >= (3 * d.Hp + 4 + 63) / 64) return;
+            if (vid == NV && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
+            if (vid >= NV) return;
             b = T2 + T1 + vid;
         }
+    } else {
+        // linear order: the 2G blocks that prepare the next step first (one lane also evaluates its Adam scalars)
+        if ((int)blockIdx.x < 2 * a.G) {
+            if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
+            if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
+            return;
+        }
+        b = blockIdx.x - 2 * a.G;
     }
     if (b < T2 + T1) {
         const bool w2 = b < T2;
