@@ -733,7 +733,10 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         if (xcd < th) b = slot < th ? xcd * th + slot : T2 + xcd * tf + (slot - th);
         else {
             const int vid = (xcd - th) * (th + tf) + slot;
-            if (vid == NV && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
+            if (vid == NV && tid == 0) {
+                sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
+                if (stamp) stamp[3] = wall_clock64();
+            }
             if (vid >= NV) return;
             b = T2 + T1 + vid;
         }

@@ -50,4 +50,7 @@ tl = wg[wg[:, 1] > 0]     # tile blocks are the ones that stamp their load / red
 for nm, k in (("operands loaded + MFMA", 1), ("LDS reduce barrier", 2), ("Adam + stores issued", 3)):
     dt = 10 * (tl[:, k] - tl[:, 0])
     print(f"wgrad tiles: {nm:24s} at +{dt.min()}..{dt.max()} ns (median {int(np.median(dt))})")
+sp = wg[(wg[:, 1] == 0) & (wg[:, 3] > 0)]
+if len(sp):
+    print(f"wgrad Adam-scalar lane (double pow): done at +{10 * int((sp[:, 3] - sp[:, 0]).max())} ns")
 _lib.check(fn(disc.h, 0, None, 0))
