@@ -651,15 +651,22 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
 }
 
 // The four weight images of k_disc_chain4 from the padded parameter vector (after sg_disc_set_params).
-__device__ __forceinline__ void sg_disc_img_store(const SgDiscDesc& d, float* img, bool is_w2, int row, int col, float p) {
+// positions of weight element (row, col) in the two images that hold it
+__device__ __forceinline__ void sg_disc_img_pos(const SgDiscDesc& d, bool is_w2, int row, int col, int& i0, int& i1) {
     const int Hp = d.Hp, Fp = d.Fp;
     if (is_w2) {
-        img[Hp * Fp + sg4_img_index(row, col, Hp)] = p;                       // W2   (n = row, k = col)
-        img[Hp * Fp + Hp * Hp + sg4_img_index(col, row, Hp)] = p;             // W2^T (n = col, k = row)
+        i0 = Hp * Fp + sg4_img_index(row, col, Hp);                       // W2   (n = row, k = col)
+        i1 = Hp * Fp + Hp * Hp + sg4_img_index(col, row, Hp);             // W2^T (n = col, k = row)
     } else {
-        img[sg4_img_index(row, col, Fp)] = p;                                 // W1
-        img[Hp * Fp + 2 * Hp * Hp + sg4_img_index(col, row, Hp)] = p;         // W1^T
+        i0 = sg4_img_index(row, col, Fp);                                 // W1
+        i1 = Hp * Fp + 2 * Hp * Hp + sg4_img_index(col, row, Hp);         // W1^T
     }
+}
+__device__ __forceinline__ void sg_disc_img_store(const SgDiscDesc& d, float* img, bool is_w2, int row, int col, float p) {
+    int i0, i1;
+    sg_disc_img_pos(d, is_w2, row, col, i0, i1);
+    img[i0] = p;
+    img[i1] = p;
 }
 __global__ __launch_bounds__(256) void k_disc_images(SgDiscDesc d, const float* params, float* img) {
     const int n1 = d.Hp * d.Fp, n2 = d.Hp * d.Hp;
@@ -800,8 +807,18 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         __syncthreads();
         if (stamp) stamp[2] = wall_clock64();
         if (tid < 256) {
+            // every address is formed before the first store: an index computed after a store would reuse the store's
+            // data registers and make the compiler wait for the store to be acknowledged (a memory round trip)
+            int img0 = 0, img1 = 0;
+            sg_disc_img_pos(d, w2, tm * 16 + (tid >> 4), tn * 16 + (tid & 15), img0, img1);
             float g = 0.f;
-            for (int w = 0; w < nw; ++w) g += red[w][tid];
+            {   // the eight partials are read with independent LDS loads, then added in a fixed order
+                float r8[SG_WGRAD_THREADS / 64];
+#pragma unroll
+                for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) r8[w] = red[w][tid];
+#pragma unroll
+                for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) g += r8[w];
+            }
             if (a.grad_out) a.grad_out[idx] = g;
             else {
                 const bool odd = (t0 + a.k1) & 1;
@@ -810,12 +827,13 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
                 v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
                 const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
                 p0 = p0 - step_size * (m0 / denom);
+                __builtin_amdgcn_sched_barrier(0);
                 a.params[idx] = p0;
                 a.m[idx] = m0;
                 a.v[idx] = v0;
+                if (a.wT) { a.wT[img0] = p0; a.wT[img1] = p0; }
             }
         }
-        if (a.wT && !a.grad_out && tid < 256) sg_disc_img_store(d, a.wT, w2, tm * 16 + (tid >> 4), tn * 16 + (tid & 15), p0);
         if (stamp) stamp[3] = wall_clock64();
     } else {
         // vectors: db1 | db2 | dw3 | db3 and the three loss sums from the per-workgroup partials.  Vector block vb
@@ -848,7 +866,13 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         __syncthreads();
         if (wave == 0 && i < NE) {
             g = 0.f;
-            for (int w = 0; w < nw; ++w) g += red[w][lane];
+            {
+                float r8[SG_WGRAD_THREADS / 64];
+#pragma unroll
+                for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) r8[w] = red[w][lane];
+#pragma unroll
+                for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) g += r8[w];
+            }
             if (i < 3 * Hp + 1) {
                 if (a.grad_out) a.grad_out[pidx] = g;
                 else {
