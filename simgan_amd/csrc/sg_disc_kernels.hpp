@@ -828,10 +828,10 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
                 const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
                 p0 = p0 - step_size * (m0 / denom);
                 __builtin_amdgcn_sched_barrier(0);
-                a.params[idx] = p0;
-                a.m[idx] = m0;
-                a.v[idx] = v0;
-                if (a.wT) { a.wT[img0] = p0; a.wT[img1] = p0; }
+                __builtin_nontemporal_store(p0, a.params + idx);
+                __builtin_nontemporal_store(m0, a.m + idx);
+                __builtin_nontemporal_store(v0, a.v + idx);
+                if (a.wT) { __builtin_nontemporal_store(p0, a.wT + img0); __builtin_nontemporal_store(p0, a.wT + img1); }
             }
         }
         if (stamp) stamp[3] = wall_clock64();
