@@ -75,6 +75,16 @@ int sg_policy_get_value(sg_policy *p, const float *obs, int n, float *value);
 /* Policy.evaluate_actions a2c/model.py:107-114: value[n], logp[n], *entropy = dist.entropy().mean() */
 int sg_policy_evaluate(sg_policy *p, const float *obs, const float *action, int n, float *value,
                        float *logp, float *entropy);
+/* The policies that live INSIDE the reference's hybrid-sim environments, batched over the N environments of a
+ * pool: every worker calls a batch-1 actor_critic.act per step, in refinement mode on one of five saved dynamics
+ * policies drawn per step (my_pybullet_envs/hopper_env_combined_policy.py:113-140,211-216,
+ * laikago_env_combined_policy.py:126-153,263-268).  ONE launch: row i of obs[n,O] goes through
+ * policies[idx[i]] (0 <= idx[i] < n_policies <= SG_ENSEMBLE_MAX, all members the same kind and shape, weights
+ * resident).  noise / seed / deterministic and the outputs are as in sg_policy_act. */
+#define SG_ENSEMBLE_MAX 8
+int sg_policy_act_ensemble(sg_policy *const *policies, int n_policies, const int32_t *idx, const float *obs,
+                           int n, const float *noise, uint64_t seed, int deterministic, float *value,
+                           float *action, float *logp);
 
 /* ------------------------------------------------------------------ rollout */
 /* RolloutStorage(num_steps, num_processes, obs_shape, action_space, rhs, feat_len) a2c/storage.py:32-56.
@@ -136,6 +146,9 @@ int sg_ppo_set_lr(sg_ppo *a, float lr);
  * (a2c/storage.py:159-162), or NULL -> device-generated from `seed`. */
 int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, uint64_t seed, float out3[3]);
 /* Adam state access for checkpoint/parity: m, v flat [n] in state_dict order; *step = t. */
+/* The permutations the last sg_ppo_update consumed ([ppo_epoch][T*N], injected or library-drawn), so a run made
+ * with the library's generator can be replayed elsewhere (the role torch.manual_seed plays for the reference). */
+int sg_ppo_last_perms(sg_ppo *a, int64_t *perms, int64_t count);
 int sg_ppo_get_adam(sg_ppo *a, float *m, float *v, int64_t n, int64_t *step);
 int sg_ppo_set_adam(sg_ppo *a, const float *m, const float *v, int64_t n, int64_t step);
 
@@ -172,6 +185,13 @@ int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, in
  * (first call: returns = reward).  n must stay the same across calls. */
 int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma, const float *masks,
                            float offset, float *reward, float *returns);
+/* Discriminator.predict_prob_single_step(s, a, s_n) a2c/algo/gail.py:212-217: prob[n] = sigmoid(D(x)) on the
+ * caller-concatenated rows x[n,F]. */
+int sg_disc_predict_prob(sg_disc *d, const float *x, int n, float *prob);
+/* The draws the last update epoch consumed: expert_perm[n_expert], policy_perm[n_policy_rows], alpha[n_alpha]
+ * (injected or library-drawn); each pointer may be NULL, each count must match the epoch's size (returned in
+ * counts3 = {n_expert, n_policy_rows, n_alpha} when counts3 != NULL). */
+int sg_disc_last_draws(sg_disc *d, int64_t *expert_perm, int64_t *policy_perm, float *alpha, int64_t counts3[3]);
 int sg_disc_reset_returns(sg_disc *d);
 int sg_disc_get_returns(sg_disc *d, float *returns, int n, int *is_none);
 int sg_disc_set_returns(sg_disc *d, const float *returns, int n);

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "sg_policy_act": (C.c_int, [H, c_float_p, C.c_int, c_float_p, C.c_uint64, C.c_int, c_float_p, c_float_p, c_float_p]),
     "sg_policy_get_value": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
     "sg_policy_evaluate": (C.c_int, [H, c_float_p, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p]),
+    "sg_policy_act_ensemble": (C.c_int, [C.POINTER(H), C.c_int, C.POINTER(C.c_int32), c_float_p, C.c_int, c_float_p, C.c_uint64,
+                                         C.c_int, c_float_p, c_float_p, c_float_p]),
     "sg_rollout_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "sg_rollout_destroy": (C.c_int, [H]),
     "sg_rollout_upload": (C.c_int, [H, C.c_int, c_float_p, C.c_int64]),
@@ -67,6 +69,7 @@ PROTOTYPES = {
     "sg_ppo_destroy": (C.c_int, [H]),
     "sg_ppo_set_lr": (C.c_int, [H, C.c_float]),
     "sg_ppo_update": (C.c_int, [H, H, c_i64_p, C.c_uint64, c_float_p]),
+    "sg_ppo_last_perms": (C.c_int, [H, c_i64_p, C.c_int64]),
     "sg_ppo_get_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, c_i64_p]),
     "sg_ppo_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
     "sg_disc_create": (C.c_int, [H, C.c_int, C.c_int, C.POINTER(H)]),
@@ -80,6 +83,8 @@ PROTOTYPES = {
     "sg_disc_update_gail_dyn": (C.c_int, [H, H, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_update_rows": (C.c_int, [H, c_float_p, C.c_int64, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
+    "sg_disc_predict_prob": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
+    "sg_disc_last_draws": (C.c_int, [H, c_i64_p, c_i64_p, c_float_p, c_i64_p]),
     "sg_disc_reset_returns": (C.c_int, [H]),
     "sg_disc_get_returns": (C.c_int, [H, c_float_p, C.c_int, c_int_p]),
     "sg_disc_set_returns": (C.c_int, [H, c_float_p, C.c_int]),
@@ -157,6 +162,7 @@ class Context:
         self.h = h
         self.device = int(device)
         self.rank, self.world = 0, 1
+        self.disc_sharded = False
 
     @staticmethod
     def default():
@@ -179,6 +185,7 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(self.lib.sg_ctx_comm_init(self.h, buf, rank, world))
         self.rank, self.world = rank, world
+        self.disc_sharded = os.environ.get("SG_DISC_DP", "") == "sharded"   # read by sg_ctx_comm_init as well
 
     def profile(self, enable):
         check(self.lib.sg_ctx_profile(self.h, 1 if enable else 0))

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from ..utils import RunningMeanStd, to_host_tensor
+from ..utils import RunningMeanStd, derive_seed, to_host_tensor
 
 
 class _Trunk(object):
@@ -42,7 +42,8 @@ class Discriminator(object):
         self.ret_rms = RunningMeanStd(shape=())  # unused field kept from a2c/algo/gail.py:51
         self._expert_id = None
         self._calls = 0
-        self.seed = 0xD15C
+        self.seed = derive_seed(seed, 0xD15C)   # DataLoader shuffle / feed_forward_generator / mixup-alpha streams
+        self._ret_n = None
         self._init_params(np.random.default_rng(seed))
 
     def __del__(self):
@@ -121,6 +122,29 @@ class Discriminator(object):
             self._expert_id = key
         return int(expert_loader.batch_size)
 
+    def _check_draws(self, B, n_policy_rows, ep, pp, al):
+        """Injected RNG artefacts cross the C ABI as bare pointers: validate their lengths and index ranges here
+        (a short array would be a host out-of-bounds read, a bad index an unchecked device gather)."""
+        n_e = self.n_expert
+        n_d = min(n_e // B, n_policy_rows // B)
+        if ep is not None:
+            assert ep.size == n_e, f"expert_perm: {ep.size} indices for {n_e} expert rows"
+            assert ep.min() >= 0 and ep.max() < n_e, "expert_perm: index out of range"
+        if pp is not None:
+            assert pp.size == n_policy_rows, f"policy_perm: {pp.size} indices for {n_policy_rows} policy rows"
+            assert pp.min() >= 0 and pp.max() < n_policy_rows, "policy_perm: index out of range"
+        if al is not None:
+            assert al.size >= n_d * B, f"alpha: {al.size} draws, the epoch consumes {n_d * B}"
+
+    def last_draws(self):
+        """(expert_perm, policy_perm, alpha) the last update epoch consumed (injected or library-drawn)."""
+        cnt = (C.c_int64 * 3)()
+        _lib.check(self.lib.sg_disc_last_draws(self.h, None, None, None, cnt))
+        ep, pp = np.empty(cnt[0], np.int64), np.empty(cnt[1], np.int64)
+        al = np.empty(cnt[2], np.float32)
+        _lib.check(self.lib.sg_disc_last_draws(self.h, _lib.i64ptr(ep), _lib.i64ptr(pp), _lib.fptr(al), None))
+        return ep, pp, al
+
     # ---------------------------------------------------------------------- updates
     def update_gail_dyn(self, expert_loader, rollouts, expert_perm=None, policy_perm=None, alpha=None):
         """a2c/algo/gail.py:154-193, one epoch -> (loss, expert_loss, policy_loss) means.
@@ -132,10 +156,13 @@ class Discriminator(object):
         ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
         pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
         al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
+        # replicated data-parallel mode permutes the union of every rank's rows
+        rows_ranged = rollouts.num_steps * rollouts.num_processes * (1 if self.ctx.disc_sharded else self.ctx.world)
+        self._check_draws(B, rows_ranged, ep, pp, al)
         self._calls += 1
         _lib.check(self.lib.sg_disc_update_gail_dyn(
             self.h, rollouts.h, B, None if ep is None else _lib.i64ptr(ep), None if pp is None else _lib.i64ptr(pp),
-            None if al is None else _lib.fptr(al), self.seed + self._calls, out, C.byref(nst)))
+            None if al is None else _lib.fptr(al), (self.seed + self._calls) & (2 ** 64 - 1), out, C.byref(nst)))
         self.last_n_steps = nst.value
         return float(out[0]), float(out[1]), float(out[2])
 
@@ -146,8 +173,10 @@ class Discriminator(object):
         step on rows assembled here: policy rows = (state | action), or for is_gail_dyn
         (obs_feat | obs[:, -a_dim:] | next_obs_feat) (a2c/algo/gail.py:102-109)."""
         ds = expert_loader.dataset
-        key = ("update", id(ds), id(obsfilt))
-        if key != self._expert_id:
+        # the reference re-applies obsfilt (VecNormalize._obfilt with the CURRENT ob_rms) to every expert batch of every
+        # call (a2c/algo/gail.py:118-120), so a filtered expert matrix is rebuilt per call; only the unfiltered one is cached
+        key = ("update", id(ds)) if obsfilt is None else None
+        if key is None or key != self._expert_id:
             es, ea = _lib.as_f32(ds.tensors[0]), _lib.as_f32(ds.tensors[1])
             if obsfilt is not None:
                 es = np.asarray(obsfilt(es, update=False), np.float32)
@@ -168,10 +197,11 @@ class Discriminator(object):
         ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
         pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
         al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
+        self._check_draws(B, rows.shape[0], ep, pp, al)
         self._calls += 1
         _lib.check(self.lib.sg_disc_update_rows(
             self.h, _lib.fptr(rows), rows.shape[0], B, None if ep is None else _lib.i64ptr(ep),
-            None if pp is None else _lib.i64ptr(pp), None if al is None else _lib.fptr(al), self.seed + self._calls,
+            None if pp is None else _lib.i64ptr(pp), None if al is None else _lib.fptr(al), (self.seed + self._calls) & (2 ** 64 - 1),
             out, C.byref(nst)))
         self.last_n_steps = nst.value
         return float(out[0]), float(out[1]), float(out[2])
@@ -182,11 +212,14 @@ class Discriminator(object):
         x = _lib.as_f32(d_in).reshape(-1, self.input_dim)
         n = x.shape[0]
         m = _lib.as_f32(masks).reshape(-1)
+        assert m.size == n, f"masks: {m.size} entries for {n} rows"
+        if self._ret_n and self._ret_n != n and self.returns is not None:   # the reference's broadcast would fail here
+            raise ValueError(f"predict_reward_combined: Discriminator.returns holds {self._ret_n} rows, got {n}")
         reward = np.empty((n, 1), np.float32)
         returns = np.empty((n, 1), np.float32)
         _lib.check(self.lib.sg_disc_predict_reward(self.h, _lib.fptr(x), n, float(gamma), _lib.fptr(m),
                                                    float(offset), _lib.fptr(reward), _lib.fptr(returns)))
-        self._last_n = n
+        self._ret_n = n
         return to_host_tensor(reward), to_host_tensor(returns)
 
     def predict_reward(self, state, action, gamma, masks, offset=0.0):
@@ -194,13 +227,32 @@ class Discriminator(object):
         d_in = np.concatenate([_lib.as_f32(state), _lib.as_f32(action)], axis=1)
         return self.predict_reward_combined(d_in, gamma, masks, offset)
 
+    def predict_prob_single_step(self, s, a, s_n):
+        """a2c/algo/gail.py:212-217: sigmoid(D(cat(s, a, s_n))) as a Python float (one transition)."""
+        x = np.concatenate([_lib.as_f32(s).reshape(-1), _lib.as_f32(a).reshape(-1), _lib.as_f32(s_n).reshape(-1)])
+        assert x.size == self.input_dim, (x.size, self.input_dim)
+        x = np.ascontiguousarray(x.reshape(1, -1))
+        out = np.empty(1, np.float32)
+        _lib.check(self.lib.sg_disc_predict_prob(self.h, _lib.fptr(x), 1, _lib.fptr(out)))
+        return float(out[0])
+
+    def predict_prob(self, d_in):
+        """Batched form of predict_prob_single_step: sigmoid(D(x)) for rows x [n, F] -> [n, 1]."""
+        x = _lib.as_f32(d_in).reshape(-1, self.input_dim)
+        out = np.empty((x.shape[0], 1), np.float32)
+        _lib.check(self.lib.sg_disc_predict_prob(self.h, _lib.fptr(x), x.shape[0], _lib.fptr(out)))
+        return to_host_tensor(out)
+
     @property
     def returns(self):
         none = C.c_int(0)
         _lib.check(self.lib.sg_disc_get_returns(self.h, None, 0, C.byref(none)))
         if none.value:
             return None
-        n = self._returns_n()
+        n = self._ret_n
+        if not n:
+            raise _lib.SimganHipError("Discriminator.returns: the handle holds returns this object never sized "
+                                      "(set through another object?); assign .returns or call predict_reward* first")
         out = np.empty((n, 1), np.float32)
         _lib.check(self.lib.sg_disc_get_returns(self.h, _lib.fptr(out), n, C.byref(none)))
         return to_host_tensor(out)
@@ -209,13 +261,11 @@ class Discriminator(object):
     def returns(self, value):
         if value is None:
             _lib.check(self.lib.sg_disc_reset_returns(self.h))
+            self._ret_n = None
         else:
             v = _lib.as_f32(value).reshape(-1)
             _lib.check(self.lib.sg_disc_set_returns(self.h, _lib.fptr(v), v.size))
             self._ret_n = v.size
-
-    def _returns_n(self):
-        return getattr(self, "_ret_n", None) or self._last_n
 
     def relabel_rewards(self, rollouts, gamma, offset, ret_rms):
         """Fused a2c/main_gail_dyn_ppo.py:275-292 over all T steps on device; ret_rms is the caller's
@@ -224,5 +274,5 @@ class Discriminator(object):
         st = (C.c_double * 3)(*ret_rms.get_state())
         _lib.check(self.lib.sg_disc_relabel_rewards(self.h, rollouts.h, float(gamma), float(offset), st))
         ret_rms.set_state([st[0], st[1], st[2]])
-        self._last_n = rollouts.num_processes
+        self._ret_n = rollouts.num_processes
         rollouts._pull([_lib.F_REWARDS])

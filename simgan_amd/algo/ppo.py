@@ -5,6 +5,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
+from ..utils import derive_seed
 
 
 class _ParamGroups(list):
@@ -48,7 +49,8 @@ class PPO():
                  max_grad_norm=None,
                  use_clipped_value_loss=True,
                  mirror_obs=None,
-                 mirror_act=None):
+                 mirror_act=None,
+                 seed=0):
         if mirror_obs and symmetry_coef > 0:
             # a2c/algo/ppo.py:110-136: never enabled by any shipped script
             raise NotImplementedError("mirror-symmetry loss is out of scope")
@@ -63,7 +65,7 @@ class PPO():
         self.symmetry_coef = symmetry_coef
         self.mirror_obs = mirror_obs
         self.mirror_act = mirror_act
-        self.is_cuda = True
+        self.is_cuda = True   # the rollout the update reads lives in HBM whatever the host tensors are
 
         self.ctx = actor_critic.ctx
         self.lib = self.ctx.lib
@@ -75,7 +77,7 @@ class PPO():
         self.h = h
         self.optimizer = _Optimizer(self, lr, eps)
         self._calls = 0
-        self.seed = 0xBADC0FFEE
+        self.seed = derive_seed(seed, 0xBADC0FFEE)   # minibatch-permutation stream (a2c/storage.py:159-162)
 
     def __del__(self):
         try:
@@ -95,9 +97,17 @@ class PPO():
         if perms is not None:
             perms = _lib.as_i64(perms).reshape(self.ppo_epoch, -1)
             assert perms.shape[1] == rollouts.num_steps * rollouts.num_processes
+            assert perms.min() >= 0 and perms.max() < perms.shape[1], "perms: row index out of range"
         _lib.check(self.lib.sg_ppo_update(self.h, rollouts.h, None if perms is None else _lib.i64ptr(perms),
-                                          self.seed + self._calls, out))
+                                          (self.seed + self._calls) & (2 ** 64 - 1), out))
+        self._last_perm_shape = (self.ppo_epoch, rollouts.num_steps * rollouts.num_processes)
         return float(out[0]), float(out[1]), float(out[2])
+
+    def last_perms(self):
+        """[ppo_epoch, T*N] permutations the last update() consumed (injected or library-drawn)."""
+        perms = np.empty(self._last_perm_shape, np.int64)
+        _lib.check(self.lib.sg_ppo_last_perms(self.h, _lib.i64ptr(perms), perms.size))
+        return perms
 
     def get_adam(self):
         n = self.actor_critic.num_params

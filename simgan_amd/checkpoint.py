@@ -5,9 +5,12 @@ The reference saves `torch.save([actor_critic, ob_rms], "<env>.pt")` and `torch.
 (my_pybullet_envs/utils.py:24-82, a2c/main.py:78-88): the files pickle the module OBJECTS, by reference to classes
 under `third_party.a2c_ppo_acktr.*`.  This module
 
-  * reads such files without the reference on the import path and without executing anything from the file: every
-    class outside torch / numpy / the standard containers is replaced by an inert stand-in that only receives its
-    `__dict__`, and the parameters are collected by walking `_parameters` / `_modules` (== `state_dict()` order);
+  * reads such files without the reference on the import path and without executing anything from the file: the
+    unpickler resolves ONLY an explicit allowlist of (module, name) pairs -- the tensor / storage / parameter
+    rebuilders, the three torch.nn layer classes and the Adam optimizer the reference's modules contain, the numpy
+    array rebuilders and the plain containers; classes under `third_party.` (the reference's own) become inert
+    stand-ins that only receive their `__dict__`; every other global (builtins.eval, os.system, torch.hub, ...) raises
+    `pickle.UnpicklingError`.  Parameters are collected by walking `_parameters` / `_modules` (== `state_dict()` order);
   * writes files the reference's `torch.load` accepts: real torch.nn layers inside objects whose classes carry the
     reference's module paths and attribute names (`base.actor`, `dist.fc_mean`, `dist.logstd._bias`, ...), in the
     legacy (non-zip) container the shipped `trained_models_*/ppo/*.pt` use.
@@ -22,7 +25,30 @@ import types
 import numpy as np
 
 REF_PKG = "third_party.a2c_ppo_acktr"
-_SAFE_ROOTS = ("torch", "collections", "numpy", "builtins", "__builtin__", "_codecs", "copyreg", "copy_reg")
+# The globals a reference checkpoint may name.  Nothing else is ever resolved (a pickle REDUCE on an allowed rebuilder
+# only constructs tensors / arrays / containers; a prefix rule such as "anything under builtins or torch" would let a
+# crafted file call builtins.eval or torch.hub.load).
+_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"),
+    ("builtins", "set"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+    ("builtins", "complex"), ("builtins", "slice"), ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "set"),
+    ("_codecs", "encode"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    ("torch.serialization", "_get_layout"), ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"),
+    ("torch.storage", "TypedStorage"),
+    ("torch.nn.modules.linear", "Linear"), ("torch.nn.modules.activation", "Tanh"),
+    ("torch.nn.modules.container", "Sequential"), ("torch.optim.adam", "Adam"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float64"), ("numpy", "float32"), ("numpy", "int64"),
+    ("types", "SimpleNamespace"),
+}
+_STUB_ROOTS = ("third_party", "a2c_ppo_acktr")   # the reference's own classes (also when imported via sys.path.append("third_party"))
+_TORCH_STORAGES = ("FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage")
+_TORCH_DTYPES = ("float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool")
 
 
 class _RefStub(object):
@@ -47,9 +73,12 @@ def _stub_class(module, name):
 
 class _StubUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] in _SAFE_ROOTS:
+        if (module, name) in _ALLOWED or (module == "torch" and (name in _TORCH_STORAGES or name in _TORCH_DTYPES)):
             return super().find_class(module, name)
-        return _stub_class(module, name)
+        if module.split(".")[0] in _STUB_ROOTS:
+            return _stub_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}, which a SimGAN checkpoint has no use "
+                                     "for: refusing to resolve it")
 
 
 def _stub_pickle_module():
@@ -103,6 +132,16 @@ def _policy_dims(class_name, sd):
     raise ValueError(f"unsupported policy class in checkpoint: {class_name}")
 
 
+def policy_from_module_state(class_name, state):
+    """The `__dict__` torch pickles for a reference `Policy` / `SplitPolicy` module (what `__setstate__` receives when
+    a bare `torch.load` of a reference checkpoint resolves the class to this package's shim through the
+    `third_party.a2c_ppo_acktr` alias modules) -> (dims dict, state_dict)."""
+    holder = _RefStub()
+    holder.__setstate__(state)
+    sd = _walk(holder, "", collections.OrderedDict())
+    return _policy_dims(class_name, sd), sd
+
+
 def read_reference_checkpoint(path):
     """`[actor_critic, ob_rms]` file -> dict(kind, obs_dim, act_dim, hidden, num_feet, class_name, state_dict, ob_rms).
     state_dict is an OrderedDict name -> float32 array in the reference's `state_dict()` order."""
@@ -152,16 +191,18 @@ def _named_params(obj, prefix=""):
 
 # ------------------------------------------------------------------------------------------ writing
 class _RefModules(object):
-    """While active, `third_party.a2c_ppo_acktr.{model,model_split,distributions,utils}` resolve to classes with the
-    reference's names, so pickle can store the objects by reference.  If the real reference is already imported its
-    own classes are used; otherwise empty torch.nn.Module subclasses are installed for the duration of the dump."""
+    """While active, `third_party.a2c_ppo_acktr.{model,model_split,distributions,utils}` resolve to torch.nn.Module
+    classes with the reference's names, so pickle can store the objects by reference.  If the real reference is already
+    imported its own classes are used; otherwise (nothing imported, or this repository's alias package whose `Policy`
+    is the device-backed shim) empty torch.nn.Module subclasses are installed for the duration of the dump and the
+    previous attributes restored afterwards."""
 
     NAMES = {"model": ["Policy", "MLPBase"], "model_split": ["SplitPolicy", "SplitPolicyBaseNew", "StateDiagGaussianNew"],
              "distributions": ["DiagGaussian"], "utils": ["AddBias"]}
 
     def __enter__(self):
         import torch
-        self.added, self.cls = [], {}
+        self.added, self.cls, self.swapped = [], {}, []
         for pkg in ("third_party", REF_PKG):
             if pkg not in sys.modules:
                 sys.modules[pkg] = types.ModuleType(pkg)
@@ -174,12 +215,19 @@ class _RefModules(object):
                 sys.modules[full] = mod
                 self.added.append(full)
             for n in names:
-                if not hasattr(mod, n):
+                cur = getattr(mod, n, None)
+                if not (isinstance(cur, type) and issubclass(cur, torch.nn.Module)):
+                    self.swapped.append((mod, n, cur))
                     setattr(mod, n, type(n, (torch.nn.Module,), {"__module__": full}))
                 self.cls[n] = getattr(mod, n)
         return self
 
     def __exit__(self, *exc):
+        for mod, n, cur in self.swapped:
+            if cur is None:
+                delattr(mod, n)
+            else:
+                setattr(mod, n, cur)
         for name in self.added:
             sys.modules.pop(name, None)
         return False

@@ -165,6 +165,7 @@ struct sg_ppo {
     float* d_state = nullptr;      // device scalars: see SgOptState
     int64_t* d_perms = nullptr;    // [ppo_epoch][T*N]
     int64_t perms_cap = 0;
+    int64_t last_perm_count = 0;   // entries of d_perms the last update consumed (sg_ppo_last_perms)
     double* d_loss_acc = nullptr;  // [3] running loss sums over the update
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
@@ -183,6 +184,7 @@ struct sg_disc {
     int64_t eperm_cap = 0, pperm_cap = 0;
     float* d_alpha = nullptr;
     int64_t alpha_cap = 0;
+    int64_t last_draws[3] = {0, 0, 0};   // entries of d_eperm / d_pperm / d_alpha the last epoch consumed
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
     int64_t opt_t = 0;             // completed Adam steps (mirrors SgOptState::t0 on the device)

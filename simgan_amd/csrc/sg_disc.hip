@@ -88,7 +88,8 @@ struct DiscFwdArgs {
     const float* x;   // [n, F]
     int n;
     float offset;
-    float* reward;    // [n]  log(s+1e-7) - log(1-s+1e-7) + offset
+    float* reward;    // [n]  log(s+1e-7) - log(1-s+1e-7) + offset   (prob != 0: sigmoid(D(x)), a2c/algo/gail.py:212-217)
+    int prob;
 };
 
 static size_t disc_fwd_lds_bytes(const SgDiscDesc& d) {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
         if (sub == 0 && base + r < a.n) {
             const float sg = sg_sigmoid(s + W[d.b3]);
-            a.reward[base + r] = logf(sg + 1e-7f) - logf(1.f - sg + 1e-7f) + a.offset;  // a2c/algo/gail.py:204-205
+            a.reward[base + r] = a.prob ? sg : logf(sg + 1e-7f) - logf(1.f - sg + 1e-7f) + a.offset;  // a2c/algo/gail.py:204-205
         }
     }
 }
@@ -393,6 +394,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     SG_TRY(ensure_cap(&d->d_erows, &d->erows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // +1: the last step's
     SG_TRY(ensure_cap(&d->d_prows, &d->prows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // "next" pointers stay in range
     d->rng_calls += 1;
+    d->last_draws[0] = d->n_expert; d->last_draws[1] = TN; d->last_draws[2] = (int64_t)n_d * batch_size;
     // expert permutation / alpha are GLOBAL (identical on every rank); the policy permutation is per rank
     if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
     else SG_TRY(sg_fill_perm(ctx, d->d_eperm, d->n_expert, seed, 0xE0000000ull + d->rng_calls));
@@ -550,10 +552,10 @@ extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t
     return disc_update_core(d, d->d_rows, n_rows, batch_size, expert_perm, policy_perm, alpha, seed, out3, n_steps);
 }
 
-static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward) {
+static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward, int prob = 0) {
     sg_ctx* ctx = d->ctx;
     DiscFwdArgs f;
-    f.d = d->desc; f.params = d->d_params; f.x = d_x; f.n = n; f.offset = offset; f.reward = d_reward;
+    f.d = d->desc; f.params = d->d_params; f.x = d_x; f.n = n; f.offset = offset; f.reward = d_reward; f.prob = prob;
     int grid = (n + 31) / 32;
     if (grid > 2 * ctx->num_cu) grid = 2 * ctx->num_cu;
     SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), f);
@@ -595,6 +597,32 @@ extern "C" int sg_disc_predict_reward(sg_disc* d, const float* x, int n, float g
     SG_CHECK(hipMemcpyAsync(reward, d_rew, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipMemcpyAsync(returns, d->d_returns, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_disc_predict_prob(sg_disc* d, const float* x, int n, float* prob) {
+    SG_REQUIRE(d && x && prob && n > 0, "sg_disc_predict_prob: bad argument");
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    float* scratch = nullptr;
+    const size_t fx = (size_t)n * d->desc.F;
+    SG_TRY(sg_ctx_scratch(ctx, sizeof(float) * (fx + (size_t)n), &scratch));
+    SG_CHECK(hipMemcpyAsync(scratch, x, sizeof(float) * fx, hipMemcpyHostToDevice, ctx->stream));
+    SG_TRY(disc_forward_dev(d, scratch, n, 0.f, scratch + fx, 1));
+    SG_CHECK(hipMemcpyAsync(prob, scratch + fx, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_disc_last_draws(sg_disc* d, int64_t* expert_perm, int64_t* policy_perm, float* alpha, int64_t counts3[3]) {
+    SG_REQUIRE(d, "sg_disc_last_draws: NULL argument");
+    SG_REQUIRE(d->last_draws[0] > 0, "sg_disc_last_draws: no update epoch has run on this discriminator");
+    if (counts3) for (int i = 0; i < 3; ++i) counts3[i] = d->last_draws[i];
+    SG_CHECK(hipSetDevice(d->ctx->device));
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    if (expert_perm) SG_CHECK(hipMemcpy(expert_perm, d->d_eperm, sizeof(int64_t) * d->last_draws[0], hipMemcpyDeviceToHost));
+    if (policy_perm) SG_CHECK(hipMemcpy(policy_perm, d->d_pperm, sizeof(int64_t) * d->last_draws[1], hipMemcpyDeviceToHost));
+    if (alpha) SG_CHECK(hipMemcpy(alpha, d->d_alpha, sizeof(float) * d->last_draws[2], hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -15,6 +15,7 @@
 #include "sg_rng.hpp"
 
 #define HALF_LOG_2PI 0.91893853320467274178f
+#define SG_ACT_STREAM 0x41435400ull
 
 // --------------------------------------------------------------------------------- forward
 
@@ -93,6 +94,7 @@ struct HeadArgs {
     int mode;             // 0: sample with noise (or RNG if noise NULL); 1: deterministic; 2: evaluate given action
     const float* noise;   // [n, A] or NULL
     uint64_t seed;
+    uint64_t stream;      // RNG stream of this call: 'ACT\0' + data-parallel rank (every rank draws its own noise)
     const float* action_in;  // mode 2
     float *value, *action, *logp, *ent;  // any may be NULL
 };
@@ -126,7 +128,7 @@ __global__ void k_gauss_head(HeadArgs a) {
         else if (a.mode == 1) act = mean;
         else {
             const float z = a.noise ? a.noise[(size_t)row * d.A + k]
-                                    : sg_normal(a.seed, 0x41435400ull, (uint64_t)row * d.A + k);
+                                    : sg_normal(a.seed, a.stream, (uint64_t)row * d.A + k);
             act = z * sigma + mean;
         }
         if (a.action) a.action[(size_t)row * d.A + k] = act;
@@ -194,7 +196,7 @@ int sg_policy_forward_device(sg_policy* p, const float* d_obs, int n, int mode, 
     SG_TRY(policy_forward_dev(p, d_obs, nullptr, n, scratch, hld));
     HeadArgs h;
     h.d = p->desc; h.params = p->d_params; h.heads = scratch; h.hld = hld; h.n = n; h.mode = mode;
-    h.noise = d_noise; h.seed = seed; h.action_in = d_action_in;
+    h.noise = d_noise; h.seed = seed; h.stream = SG_ACT_STREAM + (uint64_t)ctx->rank; h.action_in = d_action_in;
     h.value = d_value; h.action = d_action; h.logp = d_logp; h.ent = d_ent;
     hipLaunchKernelGGL(k_gauss_head, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, h);
     SG_CHECK(hipGetLastError());
@@ -311,6 +313,176 @@ extern "C" int sg_policy_act(sg_policy* p, const float* obs, int n, const float*
 extern "C" int sg_policy_get_value(sg_policy* p, const float* obs, int n, float* value) {
     SG_REQUIRE(p && obs && value, "sg_policy_get_value: NULL argument");
     return policy_host_call(p, obs, n, 1, nullptr, 0, nullptr, value, nullptr, nullptr, nullptr);
+}
+
+
+// ------------------------------------------------------------------- ensemble act
+// One launch for "row i acts with policy idx[i]" over K resident weight sets of one shape.  Block (tile, k):
+//   1. ranks the rows that drew policy k (a block-wide count + exclusive scan over idx, stable in row order) and
+//      keeps the R = 16*MT of them that belong to its tile -- blocks past the end of policy k's rows exit;
+//   2. per trunk: stages policy k's parameter block in LDS, runs the LDS-tile MFMA forward on the gathered rows;
+//   3. Gaussian head per row (sample / mode), written back at the ORIGINAL row positions.
+// Deterministic (no atomics); the noise of row i is indexed by i, so the result does not depend on the grouping.
+struct EnsArgs {
+    SgPolicyDesc d;
+    const float* params[SG_ENSEMBLE_MAX];
+    int K;
+    const int32_t* idx;   // [n]
+    const float* obs;     // [n, O]
+    int n;
+    int mode;             // 0 sample, 1 deterministic
+    const float* noise;   // [n, A] or NULL
+    uint64_t seed, stream;
+    float *value, *action, *logp;
+    int wbuf_floats, ldPmax;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void k_policy_act_ensemble(EnsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 16 * MT;
+    const SgPolicyDesc& d = a.d;
+    const int tid = threadIdx.x, k = blockIdx.y, tile = blockIdx.x;
+    float* W = smem;
+    float* X = W + a.wbuf_floats;
+    float* H1 = X + R * d.ldO;
+    float* H2 = H1 + R * d.ldH;
+    float* OUT = H2 + R * d.ldH;                       // [n_trunks][R][ldPmax]
+    int* rows = reinterpret_cast<int*>(OUT + d.n_trunks * R * a.ldPmax);   // [R]
+    int* cnt = rows + R;                               // [256] + total
+    // 1. rows of policy k, ranked in row order
+    const int chunk = (a.n + 255) / 256, lo = tid * chunk, hi = min(a.n, lo + chunk);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += (a.idx[i] == k);
+    cnt[tid] = c;
+    if (tid < R) rows[tid] = -1;
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the 256 counts by one wave: 4 per lane + a wave scan
+        int v[4], s = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = cnt[4 * tid + u]; s += v[u]; }
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+        int base = inc - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cnt[4 * tid + u] = base; base += v[u]; }
+        if (tid == 63) cnt[256] = inc;
+    }
+    __syncthreads();
+    const int total = cnt[256], first = tile * R;
+    if (first >= total) return;
+    const int nrows = min(R, total - first);
+    {
+        int rank = cnt[tid];
+        for (int i = lo; i < hi; ++i)
+            if (a.idx[i] == k) { if (rank >= first && rank < first + R) rows[rank - first] = i; ++rank; }
+    }
+    __syncthreads();
+    for (int i = tid; i < R * d.Op; i += blockDim.x) {
+        const int r = i / d.Op, cc = i - r * d.Op;
+        const int row = rows[r];
+        X[r * d.ldO + cc] = (row >= 0 && cc < d.O) ? a.obs[(size_t)row * d.O + cc] : 0.f;
+    }
+    // 2. trunks
+    for (int t = 0; t < d.n_trunks; ++t) {
+        const SgTrunk tr = d.trunk[t];
+        __syncthreads();
+        sg_stage(W, a.params[k] + tr.off, tr.size / 4);
+        __syncthreads();
+        trunk_forward<MT>(d, tr, W, X, H1, H2, OUT + t * R * a.ldPmax, tr.ldP);
+    }
+    __syncthreads();
+    // 3. heads
+    if (tid < nrows) {
+        const int row = rows[tid];
+        const float* h0 = OUT + tid * d.trunk[0].ldP;
+        const float* h1 = OUT + R * a.ldPmax + tid * d.trunk[1].ldP;
+        const float* hc = OUT + (d.n_trunks - 1) * R * a.ldPmax + tid * d.trunk[d.n_trunks - 1].ldP;
+        a.value[row] = hc[0];
+        float logp = 0.f;
+        for (int j = 0; j < d.A; ++j) {
+            float mean, ls;
+            if (d.kind == SG_POLICY_MLP) { mean = h0[j]; ls = a.params[k][d.trunk[0].off + d.trunk[0].ex + j]; }
+            else if (j < d.nc) { mean = h0[j]; ls = h0[d.nc + j]; }
+            else { mean = h1[j - d.nc]; ls = h1[d.na + j - d.nc]; }
+            const float sigma = expf(ls);
+            float act = mean;
+            if (a.mode == 0) {
+                const float z = a.noise ? a.noise[(size_t)row * d.A + j] : sg_normal(a.seed, a.stream, (uint64_t)row * d.A + j);
+                act = z * sigma + mean;
+            }
+            a.action[(size_t)row * d.A + j] = act;
+            const float diff = act - mean, var = sigma * sigma;
+            logp += -(diff * diff) / (2.0f * var) - logf(sigma) - HALF_LOG_2PI;
+        }
+        a.logp[row] = logp;
+    }
+}
+
+static size_t ens_lds_bytes(const SgPolicyDesc& d, int MT) {
+    const int R = 16 * MT;
+    return sizeof(float) * (size_t)(max_trunk_size(d, 0, d.n_trunks) + R * d.ldO + 2 * R * d.ldH + d.n_trunks * R * max_ldP(d)) +
+           sizeof(int) * (size_t)(R + 256 + 4);
+}
+
+extern "C" int sg_policy_act_ensemble(sg_policy* const* policies, int n_policies, const int32_t* idx, const float* obs,
+                                      int n, const float* noise, uint64_t seed, int deterministic, float* value,
+                                      float* action, float* logp) {
+    SG_REQUIRE(policies && idx && obs && value && action && logp, "sg_policy_act_ensemble: NULL argument");
+    SG_REQUIRE(n_policies > 0 && n_policies <= SG_ENSEMBLE_MAX, "sg_policy_act_ensemble: 1..%d policies, got %d", SG_ENSEMBLE_MAX, n_policies);
+    SG_REQUIRE(n > 0, "sg_policy_act_ensemble: n must be positive");
+    sg_policy* p0 = policies[0];
+    SG_REQUIRE(p0, "sg_policy_act_ensemble: NULL policy");
+    sg_ctx* ctx = p0->ctx;
+    const SgPolicyDesc& d = p0->desc;
+    EnsArgs a;
+    for (int k = 0; k < n_policies; ++k) {
+        SG_REQUIRE(policies[k] && policies[k]->ctx == ctx, "sg_policy_act_ensemble: member %d is NULL or lives on another context", k);
+        const SgPolicyDesc& e = policies[k]->desc;
+        SG_REQUIRE(e.kind == d.kind && e.O == d.O && e.A == d.A && e.H == d.H && e.num_feet == d.num_feet,
+                   "sg_policy_act_ensemble: member %d has a different shape", k);
+        a.params[k] = policies[k]->d_params;
+    }
+    for (int i = 0; i < n; ++i)
+        SG_REQUIRE(idx[i] >= 0 && idx[i] < n_policies, "sg_policy_act_ensemble: idx[%d] = %d outside [0, %d)", i, idx[i], n_policies);
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int O = d.O, A = d.A;
+    // device staging in the first member's io buffer: obs | noise | action | value | logp | idx
+    const size_t f_obs = (size_t)n * O, f_na = (size_t)n * A;
+    const size_t need = sizeof(float) * (f_obs + 2 * f_na + 3 * (size_t)n);
+    if (need > p0->io_bytes) {
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        if (p0->d_io) SG_CHECK(hipFree(p0->d_io));
+        SG_CHECK(hipMalloc((void**)&p0->d_io, need + need / 2));
+        p0->io_bytes = need + need / 2;
+    }
+    float* d_obs = p0->d_io;
+    float* d_noise = d_obs + f_obs;
+    float* d_action = d_noise + f_na;
+    float* d_value = d_action + f_na;
+    float* d_logp = d_value + n;
+    int32_t* d_idx = reinterpret_cast<int32_t*>(d_logp + n);
+    SG_CHECK(hipMemcpyAsync(d_obs, obs, sizeof(float) * f_obs, hipMemcpyHostToDevice, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(d_idx, idx, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (noise && !deterministic) SG_CHECK(hipMemcpyAsync(d_noise, noise, sizeof(float) * f_na, hipMemcpyHostToDevice, ctx->stream));
+    a.d = d; a.K = n_policies; a.idx = d_idx; a.obs = d_obs; a.n = n; a.mode = deterministic ? 1 : 0;
+    a.noise = (noise && !deterministic) ? d_noise : nullptr; a.seed = seed; a.stream = SG_ACT_STREAM + (uint64_t)ctx->rank;
+    a.value = d_value; a.action = d_action; a.logp = d_logp;
+    a.wbuf_floats = max_trunk_size(d, 0, d.n_trunks); a.ldPmax = max_ldP(d);
+    int MT = 2;   // 32-row tiles unless the pool is small or LDS is short
+    while (MT > 1 && (ens_lds_bytes(d, MT) > (size_t)ctx->lds_bytes - 1024 || 16 * MT * n_policies > 2 * n)) MT /= 2;
+    SG_REQUIRE(ens_lds_bytes(d, MT) <= (size_t)ctx->lds_bytes, "sg_policy_act_ensemble: policy does not fit LDS (%zu B)", ens_lds_bytes(d, MT));
+    const int R = 16 * MT;
+    const dim3 grid((n + R - 1) / R, n_policies);
+    if (MT == 2) hipLaunchKernelGGL(k_policy_act_ensemble<2>, grid, dim3(256), ens_lds_bytes(d, 2), ctx->stream, a);
+    else hipLaunchKernelGGL(k_policy_act_ensemble<1>, grid, dim3(256), ens_lds_bytes(d, 1), ctx->stream, a);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipMemcpyAsync(value, d_value, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(action, d_action, sizeof(float) * f_na, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(logp, d_logp, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int sg_policy_evaluate(sg_policy* p, const float* obs, const float* action, int n, float* value,

@@ -151,6 +151,17 @@ extern "C" int sg_ppo_set_lr(sg_ppo* a, float lr) {
     return 0;
 }
 
+extern "C" int sg_ppo_last_perms(sg_ppo* a, int64_t* perms, int64_t count) {
+    SG_REQUIRE(a && perms, "sg_ppo_last_perms: NULL argument");
+    SG_REQUIRE(a->last_perm_count > 0, "sg_ppo_last_perms: no update has run on this agent");
+    SG_REQUIRE(count == a->last_perm_count, "sg_ppo_last_perms: the last update used %lld indices, asked for %lld",
+               (long long)a->last_perm_count, (long long)count);
+    SG_CHECK(hipSetDevice(a->ctx->device));
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    SG_CHECK(hipMemcpy(perms, a->d_perms, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int sg_ppo_get_adam(sg_ppo* a, float* m, float* v, int64_t n, int64_t* step) {
     SG_REQUIRE(a && m && v && step, "sg_ppo_get_adam: NULL argument");
     const SgPolicyDesc& d = a->policy->desc;
@@ -217,6 +228,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         SG_CHECK(hipMalloc((void**)&a->d_perms, sizeof(int64_t) * (size_t)E * TN));
         a->perms_cap = (int64_t)E * TN;
     }
+    a->last_perm_count = (int64_t)E * TN;
     if (perms) {
         SG_CHECK(hipMemcpyAsync(a->d_perms, perms, sizeof(int64_t) * (size_t)E * TN, hipMemcpyHostToDevice, ctx->stream));
     } else {

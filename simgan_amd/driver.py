@@ -1,5 +1,6 @@
-"""The GAIL-dyn outer iteration (a2c/main_gail_dyn_ppo.py:201-343, row A12 of SURVEY.md section 8)
-as a reusable driver over the drop-in classes.
+"""The reference's two outer iterations (row A12 of SURVEY.md section 8) as reusable drivers over the drop-in
+classes: `GailDynLearner` = a2c/main_gail_dyn_ppo.py:201-343 (learn the hybrid simulator) and `PpoLearner` =
+a2c/main.py:199-290 (behaviour training / policy refinement: warm start, critic reset, linear LR decay, no D).
 
 The reference mains cannot run unmodified in a current environment (np.infty, whole-module
 torch.load, gym/pybullet), so this module reproduces their per-iteration call sequence:
@@ -98,3 +99,65 @@ class GailDynLearner(object):
         self.j += 1
         return {"gail_loss": gail[0], "gail_loss_e": gail[1], "gail_loss_p": gail[2], "value_loss": ppo[0],
                 "action_loss": ppo[1], "dist_entropy": ppo[2], "r_sa": r_sa}
+
+
+class PpoLearner(object):
+    """a2c/main.py:199-257, the plain-PPO caller (BASELINE.json configs[0] and configs[4]):
+
+        [lr decay :201-205] -> [rollout fill :207-244] -> get_value(obs[-1]) :246-249 -> compute_returns :251-252
+        -> PPO.update :254 -> after_update :256
+
+    Rewards are the environment's own (return-scaled by VecNormalize, simgan_amd/envs.py); the rollout's feature
+    slot carries the observation itself (`replace_obs_with_feat` with no selector is an identity copy,
+    a2c/main.py:168-169,218, my_pybullet_envs/utils.py:310-331)."""
+
+    def __init__(self, actor_critic, agent, rollouts, gamma=0.99, gae_lambda=0.95, use_gae=True,
+                 use_proper_time_limits=True, use_linear_lr_decay=False, lr=None, num_updates=None):
+        self.actor_critic, self.agent, self.rollouts = actor_critic, agent, rollouts
+        self.gamma, self.gae_lambda, self.use_gae = gamma, gae_lambda, use_gae
+        self.use_proper_time_limits = use_proper_time_limits
+        self.use_linear_lr_decay, self.lr, self.num_updates = use_linear_lr_decay, lr, num_updates
+        if use_linear_lr_decay:
+            assert lr is not None and num_updates, "linear LR decay needs the initial lr and num_updates (a2c/main.py:196-205)"
+        self.j = 0
+
+    @staticmethod
+    def warm_start(path, obs_shape, action_space, warm_start_logstd=None, ctx=None, critic_seed=1):
+        """a2c/main.py:78-88: load the behaviour policy from a reference checkpoint (its ob_rms is assumed None, :79),
+        re-initialise the critic, optionally reset the action log-std."""
+        from .checkpoint import load_policy
+        actor_critic, _ = load_policy(path, ctx=ctx)
+        actor_critic.reset_critic(obs_shape, seed=critic_seed)
+        if warm_start_logstd is not None:
+            actor_critic.reset_variance(action_space, warm_start_logstd)
+        return actor_critic
+
+    # ---------------------------------------------------------------- rollout fill (:207-244)
+    def collect(self, envs, feat_select_func=None):
+        ro, pol = self.rollouts, self.actor_critic
+        for step in range(ro.num_steps):
+            value, action, logp, hxs = pol.act(ro.obs[step], ro.recurrent_hidden_states[step], ro.masks[step])
+            obs, reward, done, infos = envs.step(action)
+            feat = obs if feat_select_func is None else feat_select_func(obs)
+            masks = np.array([[0.0] if d else [1.0] for d in done], np.float32)
+            bad = np.array([[0.0] if 'bad_transition' in info.keys() else [1.0] for info in infos], np.float32)
+            ro.insert(obs, hxs, action, logp, value, reward, to_host_tensor(masks), to_host_tensor(bad), feat)
+        if ro.device_resident:
+            ro.sync_to_device()
+
+    # ------------------------------------------------------------- the timed part (:201-205, :246-256)
+    def update(self):
+        ro, lib = self.rollouts, self.rollouts.lib
+        if self.use_linear_lr_decay:
+            update_linear_schedule(self.agent.optimizer, self.j, self.num_updates, self.lr)
+        if ro.device_resident:
+            _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, self.actor_critic.h, 1 if self.use_gae else 0,
+                                                             float(self.gamma), float(self.gae_lambda),
+                                                             1 if self.use_proper_time_limits else 0))
+        else:
+            next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
+            ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
+        value_loss, action_loss, dist_entropy = self.agent.update(ro)
+        ro.after_update()
+        self.j += 1
+        return {"value_loss": value_loss, "action_loss": action_loss, "dist_entropy": dist_entropy}

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .utils import orthogonal, to_host_tensor
+from .utils import derive_seed, orthogonal, to_host_tensor
 
 
 class _PolicyBase(object):
@@ -24,7 +24,8 @@ class _PolicyBase(object):
         n = C.c_int64(0)
         _lib.check(self.lib.sg_policy_num_params(self.h, C.byref(n)))
         self.num_params = n.value
-        self._seed = 0x5EED
+        self.seed = derive_seed(0, 0x5EED)   # action-noise stream; re-derived from the constructor seed below
+        self._act_calls = 0
 
     def __del__(self):
         try:
@@ -91,7 +92,15 @@ class _PolicyBase(object):
                 "num_feet": self.num_feet, "flat": self.get_flat_params()}
 
     def __setstate__(self, st):
+        if "_modules" in st:   # a reference whole-module pickle (a2c/main.py:81-83) resolved to this class by the alias modules
+            from .checkpoint import policy_from_module_state
+            dims, sd = policy_from_module_state(type(self).__name__, st)
+            self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], None)
+            self.seed = derive_seed(0, 0x5EED)
+            self.load_state_dict(sd)
+            return
         self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None)
+        self.seed = derive_seed(0, 0x5EED)
         self.set_flat_params(st["flat"])
 
     # ---- the three calls on the hot path
@@ -104,9 +113,9 @@ class _PolicyBase(object):
         action = np.empty((n, self.act_dim), np.float32)
         logp = np.empty((n, 1), np.float32)
         nz = None if noise is None else _lib.as_f32(noise).reshape(n, self.act_dim)
-        self._seed += 1
+        self._act_calls += 1
         _lib.check(self.lib.sg_policy_act(self.h, _lib.fptr(obs), n,
-                                          None if nz is None else _lib.fptr(nz), self._seed,
+                                          None if nz is None else _lib.fptr(nz), (self.seed + self._act_calls) & (2 ** 64 - 1),
                                           1 if deterministic else 0, _lib.fptr(value),
                                           _lib.fptr(action), _lib.fptr(logp)))
         return to_host_tensor(value), to_host_tensor(action), to_host_tensor(logp), rnn_hxs
@@ -146,6 +155,7 @@ class Policy(_PolicyBase):
             raise NotImplementedError("only Box action spaces (a2c/model.py:55-57)")
         hidden = base_kwargs.get("hidden_size", 64)
         self._create(obs_shape[0], action_space.shape[0], hidden, 1, ctx)
+        self.seed = derive_seed(seed, 0x5EED)
         self._init_params(np.random.default_rng(seed))
 
     def param_shapes(self):
@@ -180,8 +190,15 @@ class Policy(_PolicyBase):
         self.load_state_dict(sd)
 
     def reset_critic(self, obs_shape, seed=1):
-        """a2c/model.py:80-87 (the reference hard-codes a 64-unit critic; here the critic keeps
-        the policy's hidden size, which is 64 for every config that calls this)."""
+        """a2c/model.py:80-87: fresh orthogonal critic trunk + value head, zero biases.  The reference hard-codes a
+        64-unit critic whatever the actor's width; this library keeps ONE hidden size per policy, so the call is
+        only accepted where both agree (hidden_size == 64: every shipped config that warm-starts,
+        train_laika_power.sh:7) and raises otherwise instead of silently building a different network."""
+        if self.hidden_size != 64:
+            raise NotImplementedError("reset_critic: the reference rebuilds a 64-unit critic (a2c/model.py:84-86); "
+                                      f"this policy has hidden_size={self.hidden_size}")
+        if int(obs_shape[0]) != self.obs_dim:
+            raise ValueError(f"reset_critic: obs_shape {tuple(obs_shape)} != the policy's observation size {self.obs_dim}")
         rng = np.random.default_rng(seed)
         sd = self.state_dict()
         for name, shape in self.param_shapes():

@@ -49,6 +49,7 @@ class RolloutStorage(object):
         self.step = 0
         self.obs_dim, self.act_dim, self.feat_len = O, A, F
         self.device_resident = False
+        self._host_written = False   # insert() wrote host slots since the last after_update()
 
         self.ctx = ctx or _lib.Context.default()
         self.lib = self.ctx.lib
@@ -123,15 +124,20 @@ class RolloutStorage(object):
         put(self.masks[s + 1], masks)
         put(self.bad_masks[s + 1], bad_masks)
         self.step = (self.step + 1) % self.num_steps
+        self._host_written = True
 
     def after_update(self):
         """a2c/storage.py:96-101"""
         if self.device_resident:   # the device copy is the rollout; the host mirrors are refreshed by sync_from_device()
             _lib.check(self.lib.sg_rollout_after_update(self.h))
-            return
+            if not self._host_written:
+                return
+            # a host-side collector (driver.collect) filled this rollout through insert(): its next act() reads host
+            # slot 0 and its next sync_to_device() uploads it, so the host mirrors must roll over as well
         for name in ("obs", "obs_feat", "recurrent_hidden_states", "masks", "bad_masks"):
             t = getattr(self, name)
             t[0] = t[-1]
+        self._host_written = False
 
     def compute_returns(self, next_value, use_gae, gamma, gae_lambda, use_proper_time_limits=True):
         """a2c/storage.py:103-142, on device (one thread per env column, reverse scan over T)."""

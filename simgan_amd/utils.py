@@ -8,6 +8,23 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+_INSTANCES = [0]
+
+
+def derive_seed(seed, salt):
+    """RNG seed of one stochastic object: a splitmix64 hash of (constructor seed, salt, per-process instance
+    counter), so two policies / agents / discriminators never share a noise stream and a different constructor
+    seed gives different draws.  Reproducible for a fixed construction order; override with `obj.seed = x`."""
+    _INSTANCES[0] += 1
+    x = (int(seed) * 0x9E3779B97F4A7C15 + int(salt) * 0xD6E8FEB86659FD93 + _INSTANCES[0] * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    x ^= x >> 31
+    return x >> 2   # headroom: callers add a per-call counter
+
+
 def to_host_tensor(a):
     """numpy -> torch CPU tensor sharing memory (or the array itself without torch)."""
     return torch.from_numpy(a) if torch is not None else a

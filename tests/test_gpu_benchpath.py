@@ -1,0 +1,113 @@
+"""GPU: the EXACT path bench.py times, end to end against the oracle.
+
+bench.py's timed region is `GailDynLearner.update()` on a device-resident rollout with the library's own random
+draws and hipGraph replay: 5 x 512 discriminator steps, the alive-bonus offset from the device done count, the
+fused relabel, GAE with the value of obs[T] computed on device, 160 PPO steps, the device after_update.  Here the
+same object graph is built by bench.build_problem, two consecutive updates run exactly as bench.py runs them, the
+draws every phase consumed are exported (sg_disc_last_draws / sg_ppo_last_perms) and the identical two updates are
+replayed through oracle/sg_oracle.c (about a minute of one CPU core).
+
+Tolerances.  Single kernels agree with the oracle to ~1e-6; an update is a 2,720-step Adam trajectory in which fp32
+summation-order differences compound, so the post-update quantities are checked at north_star's 1e-4 relative where the
+chain is short (rewards, returns, statistics, losses) and on the trajectory-level quantities at the tolerance written
+next to each assert."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat2(a):
+    return a.numpy()[..., 0] if hasattr(a, "numpy") else np.asarray(a)[..., 0]
+
+
+def test_bench_path_two_updates_vs_oracle():
+    import bench
+    import simgan_amd as sg
+    from oracle import oracle as orc
+    from simgan_amd import _lib
+
+    w = bench.WORKLOADS["northstar"]
+    T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
+    pol, disc, agent, ro, loader, expert, learner = bench.build_problem(sg, w, seed=0)
+    lib = _lib.load()
+    _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
+    assert ro.device_resident
+
+    # record the draws of every discriminator epoch without touching what runs on the device
+    draws = []
+    real_update = disc.update_gail_dyn
+
+    def recording_update(*a, **k):
+        out = real_update(*a, **k)
+        draws.append(disc.last_draws())
+        return out
+
+    disc.update_gail_dyn = recording_update
+
+    d = orc.dims(orc.KIND_MLP, O, A, H, 1)
+    pi, dp = pol.get_flat_params(), disc.get_flat_params()
+    pi_adam, d_adam = orc.AdamState(pi.size), orc.AdamState(dp.size)
+    cfg = orc.ppo_cfg(w["clip"], w["E_p"], w["M"], 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
+    d_ret, rms = None, [0.0, 1.0, 1e-4]
+    t_orc = 0.0
+    for it in range(2):
+        ro.sync_from_device()                       # the update's input, as it sits in HBM
+        obs, obs_feat = ro.obs.numpy().copy(), ro.obs_feat.numpy().copy()
+        actions, logp = ro.actions.numpy().copy(), _flat2(ro.action_log_probs).copy()
+        vp, masks, bad = _flat2(ro.value_preds).copy(), _flat2(ro.masks).copy(), _flat2(ro.bad_masks).copy()
+        draws.clear()
+        out = learner.update()                      # == the body of bench.py's timed loop
+        perms = agent.last_perms()
+        assert len(draws) == w["E_d"] and perms.shape == (w["E_p"], T * N)
+        for ep_, pp_, al_ in draws:                 # the library's own draws are what the reference's would be: bijections, U[0,1)
+            assert np.array_equal(np.sort(ep_), np.arange(w["Ne"])) and np.array_equal(np.sort(pp_), np.arange(T * N))
+            assert al_.size == 512 * B and al_.min() >= 0.0 and al_.max() < 1.0
+        assert len({a_[0][:64].tobytes() for a_ in draws}) == w["E_d"], "every epoch must draw a fresh permutation"
+
+        # ---- the same update through the oracle (a2c/main_gail_dyn_ppo.py:255-304)
+        t0 = time.perf_counter()
+        for k, (ep_, pp_, al_) in enumerate(draws):
+            dl, n_d = orc.disc_update(F, Hd, dp, d_adam, expert, obs_feat, B, ep_, pp_, al_)
+            assert n_d == 512
+        r_sa = orc.alive_bonus(masks, T, N, 500.0)
+        rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, bench.GAMMA, -r_sa, d_ret, rms)
+        nv = orc.policy_forward(d, pi, obs[T])[0][:, 0]
+        ret, vp2 = orc.compute_returns(rewards, vp, masks, bad, nv, 1, bench.GAMMA, bench.LAM, 1)
+        pl = orc.ppo_update(d, pi, pi_adam, cfg, obs, actions, vp2, ret, logp, perms)
+        t_orc += time.perf_counter() - t0
+
+        # ---- compare
+        ro.sync_from_device()
+        tag = f"update {it}: "
+        assert_close(out["r_sa"], r_sa, rtol=1e-9, atol=0, what=tag + "alive-bonus offset (device done count)")
+        assert_close(_flat2(ro.rewards), rewards, rtol=2e-4, atol=2e-4, what=tag + "relabelled rewards")   # through D after 2,560 steps
+        assert_close(learner.ret_rms.get_state(), rms, rtol=1e-4, what=tag + "ret_rms")
+        assert_close(disc.returns.numpy()[:, 0], d_ret, rtol=2e-4, atol=2e-4, what=tag + "Discriminator.returns")
+        assert_close(_flat2(ro.value_preds)[T], nv, what=tag + "value_preds[T] = get_value(obs[T])")
+        assert_close(_flat2(ro.returns)[:T], ret[:T], rtol=2e-4, atol=2e-4, what=tag + "GAE returns")
+        assert_close([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl, what=tag + "D losses of the last epoch")
+        assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], pl, rtol=1e-4, atol=2e-5, what=tag + "PPO losses")
+        # trajectory level: 2,560 (D) / 160 (pi) Adam steps from identical starts.  Steps are lr-sized (1e-3 / 3e-4), so
+        # a parameter that moved ~0.1-1 carries the accumulated fp32 reordering noise of every step: 1e-4 relative on the
+        # weights' own scale + a 2e-4 absolute floor for the entries near zero.
+        p_hip, d_hip = pol.get_flat_params(), disc.get_flat_params()
+        assert_close(d_hip, dp, rtol=1e-4, atol=2e-4, what=tag + "D weights after 2,560 steps")
+        assert_close(p_hip, pi, rtol=1e-4, atol=5e-5, what=tag + "policy weights after 160 steps")
+        assert np.abs(dp).max() > 0.1 and np.abs(d_hip - dp).max() < 1e-3 * np.abs(dp).max()
+
+        # ---- device after_update / count_dones against numpy on the downloaded buffers
+        for name in ("obs", "obs_feat", "masks", "bad_masks"):
+            a_ = getattr(ro, name).numpy()
+            assert np.array_equal(a_[0], a_[T]), f"{tag}after_update: {name}[0] != {name}[T]"
+        assert np.array_equal(ro.obs.numpy()[1:], obs[1:]) and np.array_equal(ro.obs.numpy()[0], obs[T])
+        dones = C.c_double(0)
+        _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))
+        assert dones.value == float((1.0 - ro.masks.numpy()).sum())
+        # re-seed the oracle's state from its own results (no resynchronisation with the device between the updates)
+    print(f"oracle replay of two updates: {t_orc:.1f} s")

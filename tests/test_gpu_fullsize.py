@@ -192,3 +192,71 @@ def test_device_uniform_and_normal(world):
     _lib.check(fn(ctx.h, 2, n, 5, z.ctypes.data_as(C.c_void_p)))
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3 and np.isfinite(z).all()
     assert abs((np.abs(z) > 2).mean() - 0.0455) < 2e-3
+
+
+# ------------------------------------------------------------------ the other BASELINE.json configurations at full size
+def _filled_rollout(sg, lib, _lib, pol, T_, N_, O_, A_, F_, seed):
+    ro = sg.RolloutStorage(T_, N_, (O_,), Box((A_,)), 1, F_)
+    ro.device_resident = True
+    _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, seed, 0.01))
+    _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, 0.99, 0.95, 1))
+    ro.sync_from_device()
+    return ro
+
+
+FULL_PPO_CASES = [
+    # BASELINE.json configs[4]: Laikago policy refinement, 2048 envs -> 256 per GPU (train_laika_power.sh:7)
+    dict(id="refine", kind="mlp", O=111, A=12, H=64, f=1, N=256, M=8, clip=0.1, lr=1.5e-4),
+    # configs[1]: HopperCombinedEnv-v1 GAIL-dyn, SplitPolicy h100 as shipped (train_hopper_deform.sh:5), 256 envs
+    dict(id="hopper-split", kind="split", O=14, A=7, H=100, f=1, N=256, M=16, clip=0.2, lr=3e-4),
+    # configs[2]: LaikagoCombinedEnv-v1 GAIL-dyn, SplitPolicy h100 nf=4 (train_laika_heavy.sh:5), 512 envs
+    dict(id="laikago-split", kind="split", O=64, A=28, H=100, f=4, N=512, M=16, clip=0.2, lr=3e-4),
+]
+
+
+@pytest.mark.parametrize("c", FULL_PPO_CASES, ids=[c["id"] for c in FULL_PPO_CASES])
+def test_ppo_epoch_full_size_other_configs_vs_oracle(world, c):
+    """One full PPO epoch (num_mini_batch optimizer steps over all T*N rows) at each remaining configuration's real
+    shape -- the shape-specialised kernel instances bench.py's hopper / laikago / refine workloads launch."""
+    from oracle import oracle as orc
+    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
+    rng = np.random.default_rng(77)
+    if c["kind"] == "mlp":
+        pol = sg.Policy((c["O"],), Box((c["A"],)), base_kwargs={"recurrent": False, "hidden_size": c["H"]}, seed=31)
+    else:
+        pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31)
+    ro = _filled_rollout(sg, lib, _lib, pol, T, c["N"], c["O"], c["A"], 4, 5)
+    p0 = (pol.get_flat_params() + 0.01 * rng.standard_normal(pol.num_params)).astype(np.float32)
+    pol.set_flat_params(p0)
+    agent = sg.algo.PPO(pol, c["clip"], 1, c["M"], 0.5, 0.01, lr=c["lr"], eps=1e-5, max_grad_norm=0.5)
+    perms = rng.permutation(T * c["N"]).astype(np.int64)[None, :]
+    losses = agent.update(ro, perms=perms)
+    d = orc.dims(orc.KIND_MLP if c["kind"] == "mlp" else orc.KIND_SPLIT, c["O"], c["A"], c["H"], c["f"])
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    olosses = orc.ppo_update(d, par, adam, orc.ppo_cfg(c["clip"], 1, c["M"], 0.5, 0.01, c["lr"], 1e-5, 0.5, True), ro.obs.numpy(),
+                             ro.actions.numpy(), ro.value_preds.numpy()[..., 0], ro.returns.numpy()[..., 0],
+                             ro.action_log_probs.numpy()[..., 0], perms)
+    assert_close(losses, olosses, what=f"{c['id']}: PPO losses over the epoch")
+    assert_close(pol.get_flat_params(), par, what=f"{c['id']}: policy params after {c['M']} steps")
+    assert np.abs(par - p0).max() > 10 * c["lr"] * 0.5
+
+
+def test_disc_epoch_prefix_hopper_shape_vs_oracle(world):
+    """64 Adam steps of update_gail_dyn at the HopperCombinedEnv-v1 shape (D-in 25 = 11+3+11, hidden 100, 256 envs)."""
+    from oracle import oracle as orc
+    sg, lib, _lib, rng = world["sg"], world["lib"], world["_lib"], np.random.default_rng(12)
+    Fh, Nh, steps = 25, 256, 64
+    pol = sg.SplitPolicy((14,), Box((7,)), base_kwargs={"hidden_size": 100, "num_feet": 1}, seed=2)
+    ro = _filled_rollout(sg, lib, _lib, pol, T, Nh, 14, 7, Fh, 6)
+    expert = rng.standard_normal((steps * B, Fh)).astype(np.float32)
+    D = sg.algo.gail.Discriminator(Fh, HD, None, seed=13)
+    p0 = D.get_flat_params()
+    eperm = rng.permutation(steps * B).astype(np.int64)
+    pperm = rng.permutation(T * Nh).astype(np.int64)
+    alpha = rng.random(steps * B).astype(np.float32)
+    losses = D.update_gail_dyn(Loader(expert, B), ro, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    olosses, n_d = orc.disc_update(Fh, HD, par, adam, expert, ro.obs_feat.numpy(), B, eperm, pperm, alpha)
+    assert n_d == steps == D.last_n_steps
+    assert_close(losses, olosses, what="D losses after 64 steps (Hopper shape)")
+    assert_close(D.get_flat_params(), par, what="D params after 64 steps (Hopper shape)")

@@ -416,22 +416,56 @@ def test_checkpoint_interop_policy(sg, name, tmp_path):
     assert np.array_equal(np.concatenate([x.reshape(-1) for x in back["state_dict"].values()]), g["flat"])
 
 
-def test_policy_ensemble_batched_inference(sg):
-    """N rows, each drawing one of K policies (hopper_env_combined_policy.py:211-216): the grouped batched forwards
-    equal row-by-row batch-1 `act` calls with the same sampling noise."""
+@pytest.mark.parametrize("kind,O,A,H,f,n", [("mlp", 14, 7, 64, 1, 37), ("split", 14, 7, 100, 1, 301), ("split", 64, 28, 100, 4, 64),
+                                           ("mlp", 111, 12, 64, 1, 2048)])
+def test_policy_ensemble_one_launch_vs_oracle(sg, orc, kind, O, A, H, f, n):
+    """sg_policy_act_ensemble: N rows, each drawing one of five saved policies per step
+    (hopper_env_combined_policy.py:113-140,211-216), ONE device launch -- every row against the oracle's policy_act with
+    the weights of the member it drew."""
     from simgan_amd.ensemble import PolicyEnsemble
-    rng = np.random.default_rng(5)
-    pols = [sg.SplitPolicy((14,), Box((7,)), base_kwargs={"hidden_size": 100, "num_feet": 1}, seed=70 + k) for k in range(5)]
+    rng = np.random.default_rng(5 + n)
+    mk = (lambda k: sg.Policy((O,), Box((A,)), base_kwargs={"recurrent": False, "hidden_size": H}, seed=70 + k)) if kind == "mlp" else \
+         (lambda k: sg.SplitPolicy((O,), Box((A,)), base_kwargs={"hidden_size": H, "num_feet": f}, seed=70 + k))
+    pols = [mk(k) for k in range(5)]
+    for p_ in pols:   # widen the heads: the production init makes every member's mean nearly zero
+        p_.set_flat_params(p_.get_flat_params() + 0.05 * rng.standard_normal(p_.num_params).astype(np.float32))
     ens = PolicyEnsemble(pols)
-    obs = rng.standard_normal((37, 14)).astype(np.float32)
-    noise = rng.standard_normal((37, 7)).astype(np.float32)
-    act, ind = ens.act(obs, noise=noise, rng=np.random.default_rng(9))
-    assert act.shape == (37, 7) and set(np.unique(ind)) <= set(range(5)) and len(np.unique(ind)) > 1
-    for r in range(37):
-        _, a1, _, _ = pols[ind[r]].act(obs[r:r + 1], None, None, noise=noise[r:r + 1])
-        assert_close(act[r], np.asarray(a1)[0], rtol=1e-6, what=f"row {r}")
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    noise = rng.standard_normal((n, A)).astype(np.float32)
+    ind = rng.integers(0, 5, size=n)
+    ind[:3] = [4, 4, 0]
+    value, act, logp, ind_out = ens.act(obs, ind=ind, noise=noise, full=True)
+    assert np.array_equal(ind_out, ind)
+    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f)
+    flats = [p_.get_flat_params() for p_ in pols]
+    for k in range(5):
+        rows = np.nonzero(ind == k)[0]
+        ov, oa, olp = orc.policy_act(d, flats[k], obs[rows], noise[rows])
+        assert_close(act.numpy()[rows], oa, what=f"member {k} actions")
+        assert_close(value.numpy()[rows], ov, what=f"member {k} values")
+        assert_close(logp.numpy()[rows], olp, what=f"member {k} log-probs")
     det, _ = ens.act(obs, ind=ind, deterministic=True)
-    assert not np.allclose(det, act)
+    for k in range(5):
+        rows = np.nonzero(ind == k)[0]
+        assert_close(det[rows], orc.policy_act(d, flats[k], obs[rows])[1], what=f"member {k} mode")
+    # one member only / library noise: rows of one policy reproduce Policy.act's own launch bit for bit
+    a1, _ = ens.act(obs[:20], ind=np.full(20, 2), noise=noise[:20])
+    _, a2, _, _ = pols[2].act(obs[:20], None, None, noise=noise[:20])
+    assert_close(a1, a2.numpy(), rtol=1e-6, what="ensemble vs Policy.act")
+    z1, _ = ens.act(obs, ind=ind)
+    z2, _ = ens.act(obs, ind=ind)
+    assert np.isfinite(z1).all() and not np.array_equal(z1, z2)      # fresh draws per call
+
+
+def test_ensemble_rejects_bad_members(sg):
+    from simgan_amd.ensemble import PolicyEnsemble
+    a = sg.Policy((5,), Box((2,)), base_kwargs={"hidden_size": 8})
+    b = sg.Policy((6,), Box((2,)), base_kwargs={"hidden_size": 8})
+    with pytest.raises(AssertionError):
+        PolicyEnsemble([a, b])
+    ens = PolicyEnsemble([a, a])
+    with pytest.raises(AssertionError):
+        ens.act(np.zeros((3, 5), np.float32), ind=[0, 1, 2])
 
 
 def test_checkpoint_interop_discriminator(sg):
@@ -530,3 +564,183 @@ def test_full_iteration_golden(sg, name):
         assert_close(losses, g[f"it{j}_ppo_losses"], what="ppo losses")
         assert_close(p.get_flat_params(), g[f"it{j}_pi_params"], what="pi params")
         ro.after_update()
+
+
+# ------------------------------------------------------- the plain-PPO caller (a2c/main.py), BASELINE.json configs[4]
+def test_refine_iteration_golden(sg):
+    """a2c/main.py:78-88,199-257 through driver.PpoLearner: warm start from a reference-written checkpoint, reset_critic,
+    reset_variance, linear LR decay, two outer iterations at the Laikago refinement shape (obs 111, act 12, h64,
+    num_mini_batch 8, clip 0.1, lr 1.5e-4) with the reference's noise / permutations injected."""
+    import os
+
+    from helpers import GOLDEN
+    from simgan_amd.driver import PpoLearner
+    g = load("iter_refine")
+    m = g["meta"]
+    T, N, O, A, H = m["T"], m["N"], m["O"], m["A"], m["H"]
+    p = PpoLearner.warm_start(os.path.join(GOLDEN, "iter_refine_warm.pt"), (O,), Box((A,)), warm_start_logstd=m["warm_start_logstd"])
+    flat = p.get_flat_params()
+    na, nc = H * O + H + H * H + H, H * O + H + H * H + H + H + 1
+    assert np.array_equal(flat[:na], g["behaviour_params"][:na])                       # actor kept
+    assert np.array_equal(flat[na + nc:-A], g["behaviour_params"][na + nc:-A])         # mean head kept
+    assert np.all(flat[-A:] == np.float32(m["warm_start_logstd"]))                     # reset_variance
+    W1c = flat[na:na + H * O].reshape(H, O)                                            # reset_critic: orthogonal rows, gain sqrt2
+    assert_close(W1c @ W1c.T, 2.0 * np.eye(H), rtol=0, atol=1e-5, what="critic.0 orthogonal init")
+    assert np.all(flat[na + H * O:na + H * O + H] == 0) and not np.array_equal(W1c.reshape(-1), g["behaviour_params"][na:na + H * O])
+    p.set_flat_params(g["pi_params0"])      # the critic draw itself is torch-RNG specific: continue from the reference's
+    agent = sg.algo.PPO(p, m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], 0.5, 0.0, lr=m["lr"], eps=1e-5, max_grad_norm=0.5)
+    ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, O)
+    ro.obs[0].copy_(ro.obs.new_tensor(g["obs0"]))
+    ro.obs_feat[0].copy_(ro.obs.new_tensor(g["obs0"]))
+    learner = PpoLearner(p, agent, ro, gamma=m["gamma"], gae_lambda=m["gae_lambda"], use_linear_lr_decay=True, lr=m["lr"],
+                         num_updates=m["num_updates"])
+
+    class ScriptedEnvs:                     # plays back the transitions the reference saw
+        def __init__(self, j):
+            self.j, self.t = j, 0
+
+        def step(self, action):
+            t_, j = self.t, self.j
+            self.t += 1
+            done = g[f"it{j}_env_masks"][t_][:, 0] == 0
+            infos = [({"bad_transition": True} if b == 0 else {}) for b in g[f"it{j}_env_bad"][t_][:, 0]]
+            return ro.obs.new_tensor(g[f"it{j}_env_obs"][t_]), ro.obs.new_tensor(g[f"it{j}_env_reward"][t_]), done, infos
+
+    for j in range(m["iters"]):
+        noises = iter(g[f"it{j}_noise"])
+        real_act = p.act
+        p.act = lambda *a_, **k_: real_act(*a_, noise=next(noises), **k_)
+        learner.collect(ScriptedEnvs(j))
+        p.act = real_act
+        assert_close(ro.actions.numpy(), g[f"it{j}_actions"], what="rollout actions")
+        assert_close(ro.action_log_probs.numpy(), g[f"it{j}_action_log_probs"], what="rollout logp")
+        assert_close(ro.value_preds.numpy()[:T], g[f"it{j}_value_preds_rollout"][:T], what="rollout values")
+        assert np.array_equal(ro.obs_feat.numpy(), ro.obs.numpy())                      # identity feature copy
+        perms = iter([g[f"it{j}_ppo_perms"]])
+        real_update = agent.update
+        agent.update = lambda r_: real_update(r_, perms=next(perms))
+        out = learner.update()
+        agent.update = real_update
+        assert agent.optimizer.param_groups[0]["lr"] == pytest.approx(float(g["lrs"][j]), rel=1e-12)
+        assert_close(ro.returns.numpy()[:T], g[f"it{j}_returns"][:T], what="returns")
+        assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], g[f"it{j}_ppo_losses"], what="ppo losses")
+        assert_close(p.get_flat_params(), g[f"it{j}_pi_params"], what="pi params")
+    with pytest.raises(NotImplementedError):   # the reference's reset_critic builds a 64-unit critic whatever the actor is
+        sg.Policy((5,), Box((2,)), base_kwargs={"hidden_size": 32}).reset_critic((5,))
+
+
+def test_collect_then_update_device_resident_equals_drop_in(sg):
+    """GailDynLearner.collect() + update() twice: the device-resident fast path must train on the same rollout as the
+    drop-in (upload-per-call) mode -- in particular slot 0 after after_update (the host mirrors roll over too)."""
+    from simgan_amd.driver import GailDynLearner
+    T, N, O, A, F = 6, 8, 14, 7, 25
+    rng = np.random.default_rng(3)
+    expert = rng.standard_normal((64, F)).astype(np.float32)
+    script = [[(rng.standard_normal((N, O)).astype(np.float32), rng.standard_normal((N, 1)).astype(np.float32),
+                rng.random(N) < 0.15, rng.standard_normal((N, F)).astype(np.float32)) for _ in range(T)] for _ in range(2)]
+    noise = rng.standard_normal((2, T, N, A)).astype(np.float32)
+    obs0 = rng.standard_normal((N, O)).astype(np.float32)
+
+    class Envs:
+        def __init__(self, j):
+            self.j, self.t = j, 0
+
+        def step(self, action):
+            o, r, d_, f_ = script[self.j][self.t]
+            self.t += 1
+            return o, r, d_, [{"sas_feat": f_[i], **({"bad_transition": True} if (d_[i] and i % 2) else {})} for i in range(N)]
+
+    results = []
+    for resident in (False, True):
+        pol = sg.SplitPolicy((O,), Box((A,)), base_kwargs={"hidden_size": 100, "num_feet": 1}, seed=1)
+        disc = sg.algo.gail.Discriminator(F, 100, None, seed=2)
+        agent = sg.algo.PPO(pol, 0.2, 2, 2, 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+        disc.seed, agent.seed = 11, 12          # same library draws in both modes
+        ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F)
+        ro.device_resident = resident
+        ro.obs[0].copy_(ro.obs.new_tensor(obs0))
+        if resident:
+            ro.sync_to_device()
+        learner = GailDynLearner(pol, agent, disc, ro, expert, gail_batch_size=16, gail_epoch=2, gail_tar_length=5.0)
+        outs = []
+        for j in range(2):
+            it = iter(noise[j])
+            real_act = pol.act
+            pol.act = lambda *a_, **k_: real_act(*a_, noise=next(it), **k_)
+            learner.collect(Envs(j), lambda infos: np.stack([i["sas_feat"] for i in infos]))
+            pol.act = real_act
+            outs.append(learner.update())
+        results.append((outs, pol.get_flat_params(), disc.get_flat_params(), ro.obs.numpy()[0].copy(), ro.masks.numpy()[0].copy()))
+    (o0, p0, d0, s0, m0), (o1, p1, d1, s1, m1) = results
+    for a_, b_ in zip(o0, o1):
+        assert a_ == b_, (a_, b_)               # same kernels on the same data: bit-identical
+    assert np.array_equal(p0, p1) and np.array_equal(d0, d1) and np.array_equal(s0, s1) and np.array_equal(m0, m1)
+    assert np.array_equal(s1, script[1][T - 1][0])
+
+
+def test_predict_prob_single_step(sg, orc):
+    """a2c/algo/gail.py:212-217"""
+    rng = np.random.default_rng(8)
+    F, Hd = 25, 100
+    D = sg.algo.gail.Discriminator(F, Hd, None, seed=4)
+    x = rng.standard_normal((9, F)).astype(np.float32) * 2.0
+    par = D.get_flat_params()
+    rew, _ = orc.disc_predict_reward(F, Hd, par, x, 0.99, np.ones(9, np.float32), 0.0)
+    # reward = log(s + 1e-7) - log(1 - s + 1e-7)  =>  s = sigmoid(reward) up to the 1e-7 terms
+    s_ref = 1.0 / (1.0 + np.exp(-rew[:, 0].astype(np.float64)))
+    assert_close(D.predict_prob(x).numpy()[:, 0], s_ref, rtol=1e-4, atol=1e-6, what="sigmoid(D(x))")
+    s0 = D.predict_prob_single_step(x[0, :11], x[0, 11:14], x[0, 14:])
+    assert isinstance(s0, float) and s0 == pytest.approx(float(s_ref[0]), rel=1e-4)
+
+
+def test_bare_torch_load_through_alias_modules_gives_the_shim(sg):
+    """a2c/main.py:81-83 / my_pybullet_envs/utils.py:43-46: `torch.load(path)` of a reference whole-module checkpoint,
+    with `third_party.a2c_ppo_acktr` resolving to this repository's alias package, unpickles straight into the
+    device-backed Policy / SplitPolicy."""
+    import os
+    import subprocess
+    import sys
+
+    from helpers import GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "import simgan_amd as sg\n"
+        "sys.path.insert(0, %r)\n"
+        "from helpers import load, assert_close\n"
+        "for name in ('ckpt_policy_mlp', 'ckpt_policy_split'):\n"
+        "    g = load(name)\n"
+        "    actor_critic, ob_rms = torch.load(%r + '/' + name + '.pt', map_location='cpu', weights_only=False)\n"
+        "    assert type(actor_critic) in (sg.Policy, sg.SplitPolicy), type(actor_critic)\n"
+        "    assert np.array_equal(actor_critic.get_flat_params(), g['flat'])\n"
+        "    v, a, lp, _ = actor_critic.act(torch.from_numpy(g['obs']), None, None, deterministic=True)\n"
+        "    assert_close(a, g['action'], what='action'); assert_close(v, g['value'], what='value')\n"
+        "    if name == 'ckpt_policy_mlp':\n"
+        "        assert type(ob_rms) is sg.RunningMeanStd and np.array_equal(ob_rms.mean, g['rms_mean'])\n"
+        "print('ok')\n") % (os.path.join(root, "tests"), GOLDEN)
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_injected_draws_are_validated(sg):
+    T, N, F = 4, 8, 7
+    D = sg.algo.gail.Discriminator(F, 16, None)
+    ro = sg.RolloutStorage(T, N, (3,), Box((2,)), 1, F)
+    loader = Loader(np.zeros((40, F), np.float32), 8)
+    with pytest.raises(AssertionError, match="expert_perm"):
+        D.update_gail_dyn(loader, ro, expert_perm=np.arange(39))
+    with pytest.raises(AssertionError, match="out of range"):
+        D.update_gail_dyn(loader, ro, policy_perm=np.arange(1, 33))
+    with pytest.raises(AssertionError, match="alpha"):
+        D.update_gail_dyn(loader, ro, alpha=np.zeros(8, np.float32))
+    losses = D.update_gail_dyn(loader, ro)
+    ep, pp, al = D.last_draws()
+    assert ep.size == 40 and pp.size == 32 and al.size == 32 and np.array_equal(np.sort(pp), np.arange(32))
+    D2 = sg.algo.gail.Discriminator(F, 16, None)
+    D2.set_flat_params(np.zeros(D2.num_params, np.float32) + 0.01)
+    D.set_flat_params(np.zeros(D.num_params, np.float32) + 0.01)
+    D.set_adam(np.zeros(D.num_params), np.zeros(D.num_params), 0)
+    a_ = D.update_gail_dyn(loader, ro)
+    b_ = D2.update_gail_dyn(loader, ro, *D.last_draws())      # replaying exported draws reproduces the epoch bit for bit
+    assert a_ == b_ and np.array_equal(D.get_flat_params(), D2.get_flat_params())

@@ -1,0 +1,184 @@
+"""CPU: host-side logic around the hot path -- the drop-in import surface (alias modules), the environment-pool shard
+with VecNormalize's return scaling against a reference-generated fixture, and checkpoint-reading safety.  No GPU, no
+compute entry point of libsimgan_hip.so is called."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, assert_close, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+
+
+# ------------------------------------------------------------------------------------------ drop-in imports
+def _run(code, pythonpath):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join(pythonpath))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+
+
+def test_reference_style_imports_resolve_to_the_shim():
+    """The import block of a2c/main_gail_dyn_ppo.py:30-38 and a2c/main.py:30-35 (minus the CLI / environment modules,
+    which stay the SimGAN checkout's own) with this repository ahead on PYTHONPATH."""
+    code = (
+        "from third_party.a2c_ppo_acktr import algo, utils\n"
+        "from third_party.a2c_ppo_acktr.algo import gail\n"
+        "from third_party.a2c_ppo_acktr.model import Policy\n"
+        "from third_party.a2c_ppo_acktr.model_split import SplitPolicy\n"
+        "from third_party.a2c_ppo_acktr.storage import RolloutStorage\n"
+        "import simgan_amd as sg\n"
+        "assert Policy is sg.Policy and SplitPolicy is sg.SplitPolicy and RolloutStorage is sg.RolloutStorage\n"
+        "assert algo.PPO is sg.algo.PPO and gail.Discriminator is sg.algo.gail.Discriminator\n"
+        "assert utils.update_linear_schedule is sg.update_linear_schedule\n"
+        "assert callable(utils.get_vec_normalize) and callable(utils.cleanup_log_dir)\n"
+        "from third_party.a2c_ppo_acktr.baselines.common.running_mean_std import RunningMeanStd\n"
+        "assert RunningMeanStd is sg.RunningMeanStd\n"
+        "print('ok')\n")
+    r = _run(code, [ROOT])
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the SimGAN checkout (development container only)")
+def test_alias_package_overlays_a_simgan_checkout():
+    """With the checkout BEHIND this repository on PYTHONPATH the modules this repository does not ship (arguments,
+    the vendored baselines) still come from SimGAN, the hot-path ones from the shim."""
+    code = (
+        "import third_party.a2c_ppo_acktr as pkg\n"
+        "from third_party.a2c_ppo_acktr.arguments import get_args\n"
+        "from third_party.a2c_ppo_acktr.baselines.common import running_mean_std as r\n"
+        "from third_party.a2c_ppo_acktr.baselines import logger\n"
+        "from third_party.a2c_ppo_acktr.model import Policy\n"
+        "import simgan_amd as sg\n"
+        f"assert get_args.__code__.co_filename.startswith({REFERENCE!r}), get_args.__code__.co_filename\n"
+        f"assert logger.__file__.startswith({REFERENCE!r})\n"
+        f"assert r.__file__.startswith({ROOT!r}) and Policy is sg.Policy\n"
+        "print('ok')\n")
+    r = _run(code, [ROOT, REFERENCE])
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+# --------------------------------------------------------------------------------------- environment pools
+def test_return_normalizer_matches_vecnormalize_fixture():
+    """a2c/envs.py:120-125 / vec_normalize.py:50-58 on the scripted rewards and dones the reference was run on."""
+    from simgan_amd.envs import ReturnNormalizer
+    g = load("vecnormalize")
+    rn = ReturnNormalizer(g["raw"].shape[1], gamma=float(g["gamma"]))
+    for t in range(g["raw"].shape[0]):
+        out = rn(g["raw"][t], g["news"][t])
+        assert np.array_equal(out, g["scaled"][t]), t            # same numpy expression order: bit-exact
+        assert np.array_equal(rn.ret, g["ret"][t])
+        assert_close([rn.ret_rms.mean, rn.ret_rms.var, rn.ret_rms.count], g["rms"][t], rtol=1e-12, atol=0, what="ret_rms")
+
+
+class FakeEnv:
+    """Deterministic stand-in for a PyBullet environment: obs = f(id, step), fixed-length episodes."""
+
+    def __init__(self, gid, seed, obs_dim=5, ep_len=7):
+        self.gid, self.seed, self.obs_dim, self.ep_len, self.t, self.episodes = gid, seed, obs_dim, ep_len + gid % 3, 0, 0
+
+    def _obs(self):
+        return np.cos(np.arange(self.obs_dim) * 0.3 + self.gid + 0.1 * self.t + self.episodes).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        self.episodes += 1
+        return self._obs()
+
+    def step(self, action):
+        self.t += 1
+        done = self.t >= self.ep_len
+        info = {"bad_transition": True} if done and self.gid % 2 == 0 else {}
+        return self._obs(), float(np.sum(action)) * 0.1 + self.gid, done, info
+
+
+def test_env_pool_shards_cover_the_global_pool():
+    from simgan_amd.envs import make_vec_envs, shard_env_indices
+    assert sum((shard_env_indices(16, r, 4) for r in range(4)), []) == list(range(16))
+    with pytest.raises(AssertionError):
+        shard_env_indices(10, 0, 4)
+    whole = make_vec_envs(lambda g, s: FakeEnv(g, s), seed=100, num_processes=8, gamma=0.99)
+    shards = [make_vec_envs(lambda g, s: FakeEnv(g, s), seed=100, num_processes=8, gamma=0.99, rank=r, world=2) for r in range(2)]
+    assert [e.seed for e in shards[1].venv.envs] == [104, 105, 106, 107]      # env i is seeded seed + i (a2c/envs.py:68)
+    o_all = whole.reset().numpy()
+    o_sh = np.concatenate([s.reset().numpy() for s in shards])
+    assert np.array_equal(o_all, o_sh)
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        a = rng.standard_normal((8, 3)).astype(np.float32)
+        obs, rew, done, infos = whole.step(a)
+        parts = [s.step(a[4 * r:4 * r + 4]) for r, s in enumerate(shards)]
+        assert np.array_equal(obs.numpy(), np.concatenate([p[0].numpy() for p in parts]))     # auto-reset included
+        assert np.array_equal(done, np.concatenate([p[2] for p in parts]))
+        assert rew.shape == (8, 1) and rew.dtype.__str__() == "torch.float32"
+        assert [("bad_transition" in i) for i in infos] == [("bad_transition" in i) for p in parts for i in p[3]]
+    # return scaling uses per-pool statistics (each rank normalises with its own shard's running variance)
+    assert whole.ret_rms.count == pytest.approx(1e-4 + 12 * 8) and shards[0].ret_rms.count == pytest.approx(1e-4 + 12 * 4)
+
+
+# -------------------------------------------------------------------------------------- checkpoint safety
+class _Evil:
+    def __reduce__(self):
+        return (eval, ("__import__('os').environ.__setitem__('SG_PWNED', '1')",))
+
+
+@pytest.mark.parametrize("payload", [_Evil(), [1, {"k": _Evil()}]])
+def test_checkpoint_reader_refuses_globals_outside_the_allowlist(tmp_path, payload):
+    """A crafted `.pt` whose pickle reduces on builtins.eval (or anything else a SimGAN checkpoint has no use for) is
+    rejected before anything runs."""
+    import torch
+    from simgan_amd import checkpoint as ck
+    os.environ.pop("SG_PWNED", None)
+    for legacy in (True, False):
+        path = str(tmp_path / f"evil_{int(legacy)}.pt")
+        torch.save(payload, path, _use_new_zipfile_serialization=not legacy)
+        with pytest.raises(pickle.UnpicklingError, match="refusing to resolve"):
+            ck.read_reference_checkpoint(path)
+        assert "SG_PWNED" not in os.environ
+
+
+def test_checkpoint_reader_refuses_torch_and_os_callables(tmp_path):
+    import torch
+    from simgan_amd import checkpoint as ck
+
+    class Hub:
+        def __reduce__(self):
+            return (torch.hub.load, ("x/y", "z"))
+
+    class Sys:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    for i, obj in enumerate((Hub(), Sys())):
+        path = str(tmp_path / f"e{i}.pt")
+        torch.save([obj, None], path)
+        with pytest.raises(pickle.UnpicklingError, match="refusing to resolve"):
+            ck.read_reference_checkpoint(path)
+
+
+def test_no_fixture_carries_reference_source():
+    """A fixture is data: torch's legacy container would embed the source text of every pickled nn.Module class
+    (tools/gen_golden.py:save_legacy_without_source disables that)."""
+    needles = (b"class Policy(nn.Module)", b"class MLPBase", b"class DiagGaussian", b"class AddBias", b"class SplitPolicy",
+               b"class Discriminator", b"def forward(", b"import torch")
+    import zipfile
+    for f in sorted(os.listdir(GOLDEN)):
+        path = os.path.join(GOLDEN, f)
+        blobs = [open(path, "rb").read()]
+        if zipfile.is_zipfile(path):
+            with zipfile.ZipFile(path) as z:
+                blobs += [z.read(n) for n in z.namelist()]
+        for b in blobs:
+            for n in needles:
+                assert n not in b, f"{f} contains {n!r}"
+
+
+def test_legacy_container_fixture_is_still_legacy():
+    """The source-free regeneration keeps the coverage it was there for: the non-zip container the shipped
+    trained_models_*/ppo/*.pt use."""
+    import zipfile
+    assert not zipfile.is_zipfile(os.path.join(GOLDEN, "ckpt_policy_mlp.pt"))
+    assert zipfile.is_zipfile(os.path.join(GOLDEN, "ckpt_policy_split.pt"))

@@ -208,3 +208,48 @@ def test_full_iteration(name):
         assert_close(pi, g[f"it{j}_pi_params"], what="pi params")
         # after_update a2c/storage.py:96-101
         obs[0], obs_feat[0], masks[0], bad[0] = obs[T], obs_feat[T], masks[T], bad[T]
+
+
+def test_refine_iteration():
+    """a2c/main.py:199-257 (policy refinement: warm start, reset critic / variance, linear LR decay, no D) restated
+    with oracle calls: 2 outer iterations at the Laikago refinement shape (obs 111, act 12, h64, 8 minibatches, clip 0.1)."""
+    g = load("iter_refine")
+    m = g["meta"]
+    d = dims_of(m)
+    T, N, O, A, H = m["T"], m["N"], m["O"], m["A"], m["H"]
+    pi = g["pi_params0"].copy()
+    # warm start keeps the actor and the mean head, re-draws the critic (zero biases), resets logstd (a2c/main.py:85-87)
+    beh = g["behaviour_params"]
+    na = H * O + H + H * H + H                      # base.actor.*
+    nc = na + 1 * H + 1                             # base.critic.* + critic_linear
+    assert np.array_equal(pi[:na], beh[:na]) and not np.array_equal(pi[na:na + H * O], beh[na:na + H * O])
+    assert np.array_equal(pi[na + nc:na + nc + A * H + A], beh[na + nc:na + nc + A * H + A])
+    assert np.all(pi[-A:] == np.float32(m["warm_start_logstd"]))
+    assert np.all(pi[na + H * O:na + H * O + H] == 0) and pi[na + nc - 1] == 0
+    adam = orc.AdamState(pi.size)
+    obs = np.zeros((T + 1, N, O), np.float32)
+    masks, bad = np.ones((T + 1, N), np.float32), np.ones((T + 1, N), np.float32)
+    obs[0] = g["obs0"]
+    for j in range(m["iters"]):
+        lr = m["lr"] - m["lr"] * (j / float(m["num_updates"]))        # a2c/utils.py:68-72
+        assert lr == float(g["lrs"][j])
+        cfg = orc.ppo_cfg(m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], 0.5, 0.0, lr, 1e-5, 0.5, True)
+        actions, logp = np.zeros((T, N, A), np.float32), np.zeros((T, N), np.float32)
+        vp, rewards = np.zeros((T + 1, N), np.float32), np.zeros((T, N), np.float32)
+        for t in range(T):
+            v, a, lp = orc.policy_act(d, pi, obs[t], g[f"it{j}_noise"][t])
+            actions[t], logp[t], vp[t] = a, lp[:, 0], v[:, 0]
+            obs[t + 1] = g[f"it{j}_env_obs"][t]
+            rewards[t] = g[f"it{j}_env_reward"][t][:, 0]
+            masks[t + 1] = g[f"it{j}_env_masks"][t][:, 0]
+            bad[t + 1] = g[f"it{j}_env_bad"][t][:, 0]
+        assert_close(actions, g[f"it{j}_actions"], what="rollout actions")
+        assert_close(logp, g[f"it{j}_action_log_probs"][..., 0], what="rollout logp")
+        nv = orc.policy_forward(d, pi, obs[T])[0]
+        assert_close(nv, g[f"it{j}_next_value"], what="next_value")
+        ret, vp = orc.compute_returns(rewards, vp, masks, bad, nv[:, 0], 1, m["gamma"], m["gae_lambda"], 1)
+        assert_close(ret[:T], g[f"it{j}_returns"][:T, :, 0], what="returns")
+        losses = orc.ppo_update(d, pi, adam, cfg, obs, actions, vp, ret, logp, g[f"it{j}_ppo_perms"])
+        assert_close(losses, g[f"it{j}_ppo_losses"], what="ppo losses")
+        assert_close(pi, g[f"it{j}_pi_params"], what="pi params")
+        obs[0], masks[0], bad[0] = obs[T], masks[T], bad[T]

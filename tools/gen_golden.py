@@ -390,6 +390,30 @@ def gen_iteration(name, kind, O, A, H, f, F, Hd, T, N, B, Ne, E, M, Ed, iters, s
                          gail_tar_length=gail_tar_length, gamma=0.99, gae_lambda=0.95), **out)
 
 
+def save_legacy_without_source(obj, path):
+    """torch's legacy (non-zip) container records the SOURCE TEXT of every pickled nn.Module class next to the object
+    (torch.serialization: persistent_id -> inspect.getsource) so a later load can warn about code drift.  A fixture
+    is data, not reference source: with getsourcefile failing, torch stores None for the source instead (its own
+    documented fallback, "Couldn't retrieve source code for container") and the container is otherwise unchanged."""
+    import inspect
+    import warnings
+    real = inspect.getsourcefile
+
+    def no_source(_obj):
+        raise OSError("source capture disabled for fixtures")
+
+    inspect.getsourcefile = no_source
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.save(obj, path, _use_new_zipfile_serialization=False)
+    finally:
+        inspect.getsourcefile = real
+    blob = open(path, "rb").read()
+    for needle in (b"class Policy(nn.Module)", b"class MLPBase", b"class DiagGaussian", b"class AddBias", b"def forward("):
+        assert needle not in blob, f"{path} still embeds reference source ({needle!r})"
+
+
 # ------------------------------------------- G. checkpoint files and the expert wire format (SURVEY 8(f) N2, N4)
 def gen_checkpoints():
     """Whole-module checkpoints exactly as the reference writes them (a2c/main.py:260-269,
@@ -402,7 +426,7 @@ def gen_checkpoints():
     p = make_policy("mlp", 11, 3, 64, 1, 700)
     rms = ns.RunningMeanStd(shape=(11,))
     rms.update(np.random.RandomState(3).randn(50, 11) * 2.0 + 0.5)
-    torch.save([p, rms], os.path.join(out_dir, "ckpt_policy_mlp.pt"), _use_new_zipfile_serialization=False)
+    save_legacy_without_source([p, rms], os.path.join(out_dir, "ckpt_policy_mlp.pt"))
     obs = torch.randn(6, 11, generator=g)
     with torch.no_grad():
         v, a, lp, _ = p.act(obs, None, None, deterministic=True)
@@ -458,7 +482,118 @@ def gen_checkpoints():
          n_items=np.int64(len(sas)), first_item=np.asarray(sas[0]))
 
 
+# ------------------------------------------- H. the plain-PPO caller: a2c/main.py:78-88,199-257 (BASELINE.json configs[4])
+def gen_refine(name, O, A, H, T, N, E, M, clip, lr, num_updates, iters, logstd, seed):
+    """Policy refinement as train_laika_power.sh:7 runs it: warm start from a behaviour checkpoint, reset_critic,
+    reset_variance(--warm-start-logstd), then per outer iteration linear LR decay -> rollout -> get_value ->
+    compute_returns -> PPO.update -> after_update.  The rollout's feature slot is the observation itself
+    (replace_obs_with_feat identity, a2c/main.py:168-169,218)."""
+    out_dir = OUT
+    behaviour = make_policy("mlp", O, A, H, 1, seed)
+    warm_path = os.path.join(out_dir, name + "_warm.pt")
+    torch.save([behaviour, None], warm_path)                      # zip container: pickled objects + tensors, no source text
+    blob = open(warm_path, "rb").read()
+    assert b"class Policy(nn.Module)" not in blob and b"def forward(" not in blob
+    out = dict(behaviour_params=flat_params(behaviour))
+    actor_critic, _ = torch.load(warm_path, map_location="cpu", weights_only=False)   # a2c/main.py:81-83
+    torch.manual_seed(seed + 1)
+    actor_critic.reset_critic((O,))                               # :85
+    actor_critic.reset_variance(ns.Box(shape=(A,)), logstd)       # :86-87
+    out["pi_params0"] = flat_params(actor_critic)
+    agent = ns.PPO(actor_critic, clip, E, M, 0.5, 0.0, lr=lr, eps=1e-5, max_grad_norm=0.5)
+    g = torch.Generator().manual_seed(seed + 2)
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, O)
+    obs0 = torch.randn(N, O, generator=g)
+    ro.obs[0].copy_(obs0)
+    ro.obs_feat[0].copy_(obs0)
+    out["obs0"] = obs0.numpy().copy()
+    lrs = []
+    for j in range(iters):
+        ns.a2c_utils.update_linear_schedule(agent.optimizer, j, num_updates, lr)      # :201-205
+        lrs.append(agent.optimizer.param_groups[0]["lr"])
+        noises, envs = [], []
+        for step in range(T):                                     # :207-244
+            with torch.no_grad():
+                torch.manual_seed(seed + 100 + 1000 * j + step)
+                noises.append(torch.randn(N, A).numpy())
+                torch.manual_seed(seed + 100 + 1000 * j + step)
+                value, action, logp, hxs = actor_critic.act(ro.obs[step], ro.recurrent_hidden_states[step], ro.masks[step])
+            obs = torch.randn(N, O, generator=g)
+            reward = torch.randn(N, 1, generator=g)
+            masks = (torch.rand(N, 1, generator=g) > 0.1).float()
+            bad = (torch.rand(N, 1, generator=g) > 0.05).float()
+            envs.append((obs.numpy().copy(), reward.numpy().copy(), masks.numpy().copy(), bad.numpy().copy()))
+            ro.insert(obs, hxs, action, logp, value, reward, masks, bad, obs.clone())
+        out[f"it{j}_noise"] = np.stack(noises)
+        for i, nm in enumerate(("env_obs", "env_reward", "env_masks", "env_bad")):
+            out[f"it{j}_{nm}"] = np.stack([e[i] for e in envs])
+        out[f"it{j}_actions"] = ro.actions.numpy().copy()
+        out[f"it{j}_action_log_probs"] = ro.action_log_probs.numpy().copy()
+        out[f"it{j}_value_preds_rollout"] = ro.value_preds.numpy().copy()
+        with torch.no_grad():
+            nv = actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()   # :246-249
+        out[f"it{j}_next_value"] = nv.numpy().copy()
+        ro.compute_returns(nv, True, 0.99, 0.95, True)            # :251-252
+        out[f"it{j}_returns"] = ro.returns.numpy().copy()
+        _REC.clear()
+        torch.manual_seed(seed + 900 + j)
+        losses = agent.update(ro)                                 # :254
+        out[f"it{j}_ppo_perms"] = np.stack([r for k, r in _REC if k == "randperm"]).astype(np.int64)
+        out[f"it{j}_ppo_losses"] = np.array(losses, np.float64)
+        out[f"it{j}_pi_params"] = flat_params(actor_critic)
+        ro.after_update()                                         # :256
+    save(name, meta=meta(kind="mlp", O=O, A=A, H=H, num_feet=1, T=T, N=N, ppo_epoch=E, num_mini_batch=M, clip_param=clip,
+                         lr=lr, num_updates=num_updates, iters=iters, warm_start_logstd=logstd, gamma=0.99, gae_lambda=0.95),
+         lrs=np.array(lrs, np.float64), **out)
+
+
+def gen_vecnormalize():
+    """VecNormalize(ob=False, ret=True).step_wait reward scaling (a2c/envs.py:120-125, vec_normalize.py:50-58) on a
+    scripted vectorised environment: inputs (raw rewards, dones) and outputs (scaled rewards, ret, ret_rms) per step."""
+    from third_party.a2c_ppo_acktr.envs import VecNormalize
+    n, steps = 6, 40
+    r = np.random.RandomState(17)
+    script = [((r.randn(n) * (1.0 + 0.2 * t)).astype(np.float32), r.rand(n) < 0.15) for t in range(steps)]
+
+    class Scripted:
+        num_envs = n
+        observation_space = ns.Box(shape=(3,))
+        action_space = ns.Box(shape=(2,))
+        t = 0
+
+        def step_wait(self):
+            rews, news = script[self.t]
+            self.t += 1
+            return np.zeros((n, 3), np.float32), rews.copy(), news.copy(), [{} for _ in range(n)]
+
+        def reset(self):
+            return np.zeros((n, 3), np.float32)
+
+    vn = VecNormalize(Scripted(), gamma=0.99, ob=False)
+    vn.reset()
+    outs, rets, states = [], [], []
+    for t in range(steps):
+        _, rews, _, _ = vn.step_wait()
+        outs.append(np.asarray(rews).copy())
+        rets.append(vn.ret.copy())
+        states.append([vn.ret_rms.mean, vn.ret_rms.var, vn.ret_rms.count])
+    save("vecnormalize", raw=np.stack([s_[0] for s_ in script]), news=np.stack([s_[1] for s_ in script]),
+         scaled=np.stack(outs), ret=np.stack(rets), rms=np.array(states, np.float64), gamma=np.float64(0.99))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # regenerate selected fixtures only: python tools/gen_golden.py refine vecnormalize checkpoints
+        for what in sys.argv[1:]:
+            if what == "refine":
+                gen_refine("iter_refine", O=111, A=12, H=64, T=8, N=16, E=2, M=8, clip=0.1, lr=1.5e-4, num_updates=4, iters=2,
+                           logstd=-1.3, seed=600)
+            elif what == "vecnormalize":
+                gen_vecnormalize()
+            elif what == "checkpoints":
+                gen_checkpoints()
+            else:
+                raise SystemExit(f"unknown fixture group {what}")
+        sys.exit(0)
     gen_policy("policy_mlp_tiny", "mlp", 5, 2, 8, 1, 16, 100)
     gen_policy("policy_mlp_northstar", "mlp", 47, 12, 64, 1, 24, 110)
     gen_policy("policy_mlp_hopper", "mlp", 11, 3, 64, 1, 8, 120)
@@ -483,3 +618,5 @@ if __name__ == "__main__":
     gen_iteration("iter_mlp", "mlp", 47, 12, 64, 1, F=86, Hd=100, T=8, N=16, B=32, Ne=200, E=2, M=2, Ed=2, iters=2, seed=500)
     gen_checkpoints()
     gen_iteration("iter_split", "split", 14, 7, 100, 1, F=25, Hd=100, T=8, N=16, B=32, Ne=100, E=2, M=2, Ed=2, iters=2, seed=510)
+    gen_refine("iter_refine", O=111, A=12, H=64, T=8, N=16, E=2, M=8, clip=0.1, lr=1.5e-4, num_updates=4, iters=2, logstd=-1.3, seed=600)
+    gen_vecnormalize()
