@@ -29,11 +29,28 @@ class _PolicyBase(object):
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.sg_policy_destroy(self.h)
-                self.h = None
+            h = self.__dict__.get("h")
+            if h:
+                self.__dict__["lib"].sg_policy_destroy(h)
+                self.__dict__["h"] = None
         except Exception:
             pass
+
+    def __getattr__(self, name):
+        # Only reached for attributes that are not set: an object torch.load is still assembling (see __setstate__)
+        # builds its device twin on first use.
+        if not name.startswith("__") and self.__dict__.get("_pending") is not None:
+            self._materialise()
+            return getattr(self, name)
+        raise AttributeError(name)
+
+    def _materialise(self):
+        from .checkpoint import policy_from_module_state
+        st = self.__dict__.pop("_pending")
+        dims, sd = policy_from_module_state(type(self).__name__, st)
+        self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], None)
+        self.seed = derive_seed(0, 0x5EED)
+        self.load_state_dict(sd)
 
     # ---- nn.Module-ish surface the reference mains touch
     @property
@@ -92,12 +109,10 @@ class _PolicyBase(object):
                 "num_feet": self.num_feet, "flat": self.get_flat_params()}
 
     def __setstate__(self, st):
-        if "_modules" in st:   # a reference whole-module pickle (a2c/main.py:81-83) resolved to this class by the alias modules
-            from .checkpoint import policy_from_module_state
-            dims, sd = policy_from_module_state(type(self).__name__, st)
-            self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], None)
-            self.seed = derive_seed(0, 0x5EED)
-            self.load_state_dict(sd)
+        if "_modules" in st:   # a reference whole-module pickle (a2c/main.py:81-83) resolved to this class by the alias modules.
+            # torch's legacy container fills the tensors' storages only AFTER the whole object graph is unpickled, so the
+            # weights are read when the policy is first used, not here.
+            self.__dict__["_pending"] = st
             return
         self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None)
         self.seed = derive_seed(0, 0x5EED)
