@@ -8,7 +8,11 @@ rollout (a2c/main_gail_dyn_ppo.py:255-302, a2c/ = third_party/a2c_ppo_acktr/):
 Inputs (rollout, expert matrix, weights, optimizer state) are resident in HBM before the timed
 region starts; nothing is skipped inside it.
 
-    python bench.py --gpus N --steps K --warmup W [--workload northstar|hopper|laikago]
+    python bench.py --gpus N --steps K --warmup W [--workload northstar|hopper|laikago|refine]
+
+`--workload refine` is the plain-PPO caller (a2c/main.py:199-257, BASELINE.json configs[4]: Laikago policy refinement,
+2048 envs -> 256 per GPU, obs 111, 8 minibatches, clip 0.1, lr 1.5e-4 with linear decay): no discriminator, one step =
+get_value + GAE + PPO.update + after_update.
 
 N > 1: launched by torch.distributed.run, one process per GPU; control plane (barrier, id
 broadcast, max-over-ranks) on gloo, data plane (gradient all-reduce) on RCCL inside the library.
@@ -35,6 +39,9 @@ WORKLOADS = {
     # BASELINE.json configs[2] real shapes: LaikagoCombinedEnv-v1, SplitPolicy h100 nf=4
     "laikago": dict(kind="split", T=128, N=512, O=64, A=28, F=86, H=100, feet=4, Hd=100, E_p=10, M=16, E_d=5,
                     B=128, Ne=100000, clip=0.2),
+    # BASELINE.json configs[4]: Laikago policy refinement (train_laika_power.sh:7), main.py caller, no discriminator
+    "refine": dict(kind="mlp", T=128, N=256, O=111, A=12, F=111, H=64, feet=1, Hd=100, E_p=10, M=8, E_d=0,
+                   B=128, Ne=0, clip=0.1, lr=1.5e-4),
 }
 GAMMA, LAM = 0.99, 0.95
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -55,7 +62,7 @@ def algorithmic_work(w, world):
     """Per-update algorithmic FLOPs and HBM bytes for ONE rank (SURVEY.md 8(d) formulas)."""
     T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
     TN = T * N
-    n_d = min(w["Ne"] // B, TN * world // B)
+    n_d = min(w["Ne"] // B, TN * world // B) if w["E_d"] else 0
     Wd = F * Hd + Hd * Hd + Hd
     d_flops_triple = 2 * (8 * Wd + F * Hd + 4 * Hd * Hd + Hd)
     if w["kind"] == "mlp":
@@ -70,25 +77,29 @@ def algorithmic_work(w, world):
     d_wgrad_flops = (B // world) * 2 * 4 * (F * Hd + Hd * Hd)   # dW1, dW2 over expert + policy + 2 mixup terms
     d_chain_flops = d_step_flops - d_wgrad_flops                 # forward + activation backward + double backward
     ppo_step_flops = mb * ppo_flops_row
-    relabel_flops = TN * 2 * Wd
+    relabel_flops = TN * 2 * Wd if w["E_d"] else 0
     flops = w["E_d"] * n_d * d_step_flops + w["E_p"] * w["M"] * ppo_step_flops + relabel_flops
-    bytes_ = (w["E_d"] * n_d * 2 * (B // world) * F * 4 + TN * (F + 2) * 4 + TN * 20 + TN * 12 +
+    bytes_ = (w["E_d"] * n_d * 2 * (B // world) * F * 4 + (TN * (F + 2) * 4 if w["E_d"] else 0) + TN * 20 + TN * 12 +
               w["E_p"] * w["M"] * mb * (O + A + 4) * 4)
     return dict(n_d=n_d, d_step_flops=d_step_flops, d_chain_flops=d_chain_flops, d_wgrad_flops=d_wgrad_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
                 d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"])
 
 
 def build_problem(sg, w, seed):
-    from simgan_amd.driver import ExpertLoader, GailDynLearner
+    from simgan_amd.driver import ExpertLoader, GailDynLearner, PpoLearner
     rng = np.random.default_rng(seed)
+    lr = w.get("lr", 3e-4)
     if w["kind"] == "mlp":
         pol = sg.Policy((w["O"],), Box((w["A"],)), base_kwargs={"recurrent": False, "hidden_size": w["H"]}, seed=seed)
     else:
         pol = sg.SplitPolicy((w["O"],), Box((w["A"],)), base_kwargs={"hidden_size": w["H"], "num_feet": w["feet"]}, seed=seed)
-    disc = sg.algo.gail.Discriminator(w["F"], w["Hd"], None, seed=seed)
-    agent = sg.algo.PPO(pol, w["clip"], w["E_p"], w["M"], 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    agent = sg.algo.PPO(pol, w["clip"], w["E_p"], w["M"], 0.5, 0.0, lr=lr, eps=1e-5, max_grad_norm=0.5)
     ro = sg.RolloutStorage(w["T"], w["N"], (w["O"],), Box((w["A"],)), 1, w["F"])
     ro.device_resident = True
+    if not w["E_d"]:   # a2c/main.py: PPO only, linear LR decay over the run's updates (train_laika_power.sh:7)
+        learner = PpoLearner(pol, agent, ro, gamma=GAMMA, gae_lambda=LAM, use_linear_lr_decay=True, lr=lr, num_updates=1000)
+        return pol, None, agent, ro, None, None, learner
+    disc = sg.algo.gail.Discriminator(w["F"], w["Hd"], None, seed=seed)
     expert = rng.standard_normal((w["Ne"], w["F"])).astype(np.float32)   # identical on every rank (same seed)
     loader = ExpertLoader(expert, w["B"])
     disc._bind_loader(loader)          # expert matrix resident in HBM before anything is timed
@@ -97,53 +108,85 @@ def build_problem(sg, w, seed):
     return pol, disc, agent, ro, loader, expert, learner
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(w, expert, budget_s):
-    """Times the CPU oracle (oracle/sg_oracle.c, kind "port") single-threaded on a bounded sample of
-    the same workload and scales to a full update."""
+    """Times the CPU oracle (oracle/sg_oracle.c, kind "port") on a bounded sample of the same workload: real
+    discriminator steps at the gail batch size and real PPO steps on full-size minibatches, first on ONE thread (the
+    reference learner runs torch.set_num_threads(1), a2c/main.py:65) and then with the rows of every step split over all
+    host cores (OpenMP); each leg's per-step times are multiplied by the update's step counts."""
     from oracle import oracle as orc
     rng = np.random.default_rng(1)
     T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
     work = algorithmic_work(w, 1)
-    # --- discriminator steps
-    dpar = (rng.standard_normal(orc.disc_num_params(F, Hd)) * 0.1).astype(np.float32)
-    adam = orc.AdamState(dpar.size)
-    e = expert[:B]
-    p = rng.standard_normal((B, F)).astype(np.float32)
-    al = rng.random(B).astype(np.float32)
-    n_dsteps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s * 0.6 or n_dsteps < 2:
-        G, _ = orc.disc_grad_rows(F, Hd, dpar, e, p, al, 1.0 / B)
-        orc.adam_step(dpar, G, adam, 1e-3, 1e-8)
-        n_dsteps += 1
-    t_d = (time.perf_counter() - t0) / n_dsteps
-    # --- PPO minibatch steps on a row sample
+    cores = os.cpu_count() or 1
     kind = orc.KIND_MLP if w["kind"] == "mlp" else orc.KIND_SPLIT
     d = orc.dims(kind, O, A, H, w["feet"])
-    ppar = (rng.standard_normal(orc.policy_num_params(d)) * 0.1).astype(np.float32)
-    padam = orc.AdamState(ppar.size)
     mb = T * N // w["M"]
-    rows_s = min(mb, 512)
-    obs = rng.standard_normal((rows_s, O)).astype(np.float32)
-    act = rng.standard_normal((rows_s, A)).astype(np.float32)
-    z = rng.standard_normal((4, rows_s)).astype(np.float32)
-    cfg = orc.ppo_cfg(w["clip"], 1, 1, 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
-    n_p, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s * 0.3 or n_p < 1:
-        G, _ = orc.ppo_grad_rows(d, ppar, cfg, obs, act, z[0], z[1], z[2] - 20.0, z[3], np.arange(rows_s), 1.0 / rows_s)
-        orc.ppo_apply(ppar, G, padam, cfg)
-        n_p += 1
-    t_p = (time.perf_counter() - t0) / n_p * (mb / rows_s)
-    # --- relabel forward on a row sample
+    obs = rng.standard_normal((mb, O)).astype(np.float32)
+    act = rng.standard_normal((mb, A)).astype(np.float32)
+    z = rng.standard_normal((4, mb)).astype(np.float32)
+    cfg = orc.ppo_cfg(w["clip"], 1, 1, 0.5, 0.0, w.get("lr", 3e-4), 1e-5, 0.5, True)
+    rows = np.arange(mb)
     x = rng.standard_normal((2048, F)).astype(np.float32)
-    t0 = time.perf_counter()
-    orc.disc_predict_reward(F, Hd, dpar, x, GAMMA, np.ones(2048, np.float32), 0.0)
-    t_r = (time.perf_counter() - t0) * (T * N / 2048)
-    est = work["d_steps"] * t_d + work["ppo_steps"] * t_p + t_r
-    return dict(value=round(T * N / est, 1), unit="env-steps/s", cores=1, kind="port",
-                sample=(f"{n_dsteps} discriminator steps (batch {B}) + {n_p} PPO steps on {rows_s}-row minibatch samples + "
-                        f"2048-row relabel forward, scaled to {work['d_steps']} + {work['ppo_steps']} steps per update; "
-                        f"{1e3 * t_d:.2f} ms/D-step, {1e3 * t_p:.1f} ms/PPO-step"),
-                reference_pytorch_cpu_env_steps_s=4627.0)
+    if w["E_d"]:
+        dpar = (rng.standard_normal(orc.disc_num_params(F, Hd)) * 0.1).astype(np.float32)
+        e, p, al = expert[:B], rng.standard_normal((B, F)).astype(np.float32), rng.random(B).astype(np.float32)
+
+    def leg(threads, budget):
+        t_d, n_dsteps = 0.0, 0
+        if w["E_d"]:
+            par, adam = dpar.copy(), orc.AdamState(dpar.size)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < budget * 0.55 or n_dsteps < 2:
+                G, _ = (orc.disc_grad_rows(F, Hd, par, e, p, al, 1.0 / B) if threads == 1 else
+                        orc.disc_grad_rows_mt(F, Hd, par, e, p, al, 1.0 / B, min(threads, B)))
+                orc.adam_step(par, G, adam, 1e-3, 1e-8)
+                n_dsteps += 1
+            t_d = (time.perf_counter() - t0) / n_dsteps
+        ppar = (rng.standard_normal(orc.policy_num_params(d)) * 0.1).astype(np.float32)
+        padam = orc.AdamState(ppar.size)
+        n_p, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget * (0.4 if w["E_d"] else 0.95) or n_p < 1:
+            a_ = (d, ppar, cfg, obs, act, z[0], z[1], z[2] - 20.0, z[3], rows, 1.0 / mb)
+            G, _ = orc.ppo_grad_rows(*a_) if threads == 1 else orc.ppo_grad_rows_mt(*a_, threads)
+            orc.ppo_apply(ppar, G, padam, cfg)
+            n_p += 1
+        t_p = (time.perf_counter() - t0) / n_p
+        t_r = 0.0
+        if w["E_d"]:   # relabel forward on a 2048-row sample (single-threaded in both legs: < 1 % of the update)
+            t0 = time.perf_counter()
+            orc.disc_predict_reward(F, Hd, dpar, x, GAMMA, np.ones(2048, np.float32), 0.0)
+            t_r = (time.perf_counter() - t0) * (T * N / 2048)
+        est = work["d_steps"] * t_d + work["ppo_steps"] * t_p + t_r
+        return dict(value=round(T * N / est, 1), cores=threads,
+                    sample=(f"{n_dsteps} discriminator steps (batch {B}) + {n_p} PPO steps on {mb}-row minibatches"
+                            f"{' + a 2048-row relabel forward' if w['E_d'] else ''}, scaled to {work['d_steps']} + {work['ppo_steps']} "
+                            f"steps per update; {1e3 * t_d:.2f} ms/D-step, {1e3 * t_p:.1f} ms/PPO-step"))
+
+    one = leg(1, budget_s * 0.6)
+    out = dict(value=one["value"], unit="env-steps/s", cores=1, kind="port", sample=one["sample"], cpu_model=_cpu_model(),
+               note=("single-threaded C restatement of the update (parity oracle); the reference's own PyTorch-CPU path, "
+                     "1 thread, measured 4,627 env-steps/s on the north-star shape in the development container "
+                     "(BASELINE.md section 2) -- it cannot be re-timed here because the reference does not travel"),
+               reference_pytorch_cpu_env_steps_s=4627.0)
+    if cores > 1:
+        # the rows of one step (128 row triples / 4096 rows) do not feed hundreds of threads: try a few team sizes up to
+        # every host core and report the fastest beside the table of what was tried
+        sizes = sorted({c for c in (8, 16, 32, 64, cores) if c <= cores})
+        tried = [leg(c, budget_s * 0.4 / len(sizes)) for c in sizes]
+        best = max(tried, key=lambda r: r["value"])
+        out["all_cores"] = dict(value=best["value"], unit="env-steps/s", cores=best["cores"], host_cores=cores, sample=best["sample"],
+                                tried={str(r["cores"]): r["value"] for r in tried})
+    return out
 
 
 def main():
@@ -202,30 +245,37 @@ def main():
         env_steps = w["T"] * w["N"] * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = env_steps * args.steps / elapsed
-        dg_ms, dg_n = prof["disc_chain"]
+        dom = "disc_chain" if w["E_d"] else "ppo_bwd"    # the kernel most of the update's time goes to
+        dom_kernel = ("k_disc_chain4" if w["E_d"] else "k_ppo_bwd")
+        dom_flops = work["d_chain_flops"] if w["E_d"] else work["ppo_step_flops"]
+        dg_ms, dg_n = prof[dom]
         dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
-        achieved = work["d_chain_flops"] / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
+        achieved = dom_flops / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
         name, num_cu, hbm = ctx.device_info()
         traffic = None   # PMC passes cannot run inside the timed process: the committed summary of the last profile run
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
-                traffic = json.load(f)["kernels"]["k_disc_chain4"]["hbm_bytes_per_launch"] if args.workload == "northstar" else None
+                traffic = json.load(f)["kernels"][dom_kernel]["hbm_bytes_per_launch"] if args.workload == "northstar" else None
         except (OSError, KeyError, ValueError):
             traffic = None
         out = {
-            "metric": "env-steps/sec of GAIL-dyn PPO update", "value": round(value, 1), "unit": "env-steps/s",
+            "metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else "env-steps/sec of PPO update (policy refinement, a2c/main.py)", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: GAIL-dyn update, T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
-                                   f"D-in={w['F']} policy={w['kind']} h{w['H']} D h{w['Hd']} ppo_epoch={w['E_p']} "
-                                   f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}",
+            "config": {"workload": (f"{args.workload}: GAIL-dyn update, T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
+                                    f"D-in={w['F']} policy={w['kind']} h{w['H']} D h{w['Hd']} ppo_epoch={w['E_p']} "
+                                    f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}") if w["E_d"] else
+                                   (f"{args.workload}: PPO update (a2c/main.py caller), T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
+                                    f"policy={w['kind']} h{w['H']} ppo_epoch={w['E_p']} num_mini_batch={w['M']} clip={w['clip']} "
+                                    f"lr={w['lr']} linear decay"),
                        "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_disc_chain4", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": dom_kernel, "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)", "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
-                         "algorithmic_flops_per_launch": work["d_chain_flops"],
-                         "note": "serial chain of 7 dependent GEMM phases on 96 four-row workgroups per 128-row step: latency-bound, see DESIGN.md section 4",
+                         "algorithmic_flops_per_launch": dom_flops,
+                         "note": ("serial chain of 7 dependent GEMM phases on 96 four-row workgroups per 128-row step: latency-bound, see DESIGN.md section 4"
+                                  if w["E_d"] else "fused forward + loss + backward + weight gradients of one minibatch, one row group per workgroup"),
                          "whole_update": {"TFLOP/s": round(work["flops"] * args.steps / elapsed / 1e12, 3),
                                           "GB/s": round(work["bytes"] * args.steps / elapsed / 1e9, 2),
                                           "frac_mfma": round(work["flops"] * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),

@@ -167,6 +167,36 @@ def ppo_grad_rows(d, params, cfg, obs, actions, value_preds, returns, old_logp, 
     return G, np.array(list(sums))
 
 
+def ppo_grad_rows_mt(d, params, cfg, obs, actions, value_preds, returns, old_logp, adv, rows, inv_B, n_threads):
+    """All-cores form of ppo_grad_rows (bench.py's cpu_baseline leg only)."""
+    params, pp = _f(params)
+    obs, po = _f(obs)
+    actions, pa = _f(actions)
+    value_preds, pv = _f(value_preds)
+    returns, pr = _f(returns)
+    old_logp, pl = _f(old_logp)
+    adv, pad = _f(adv)
+    rows, prow = _i64(rows)
+    G = np.zeros(params.size, np.float32)
+    sums = (C.c_double * 3)(0, 0, 0)
+    lib().orc_ppo_grad_rows_mt(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
+                               int(rows.size), C.c_float(inv_B), _fp(G), sums, int(n_threads))
+    return G, np.array(list(sums))
+
+
+def disc_grad_rows_mt(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, n_threads, lambda_=10.0):
+    params, pp = _f(params)
+    expert_rows, pe = _f(expert_rows)
+    policy_rows, ppol = _f(policy_rows)
+    alpha, pal = _f(alpha)
+    nb = expert_rows.shape[0]
+    G = np.zeros(params.size, np.float32)
+    sums = (C.c_double * 3)(0, 0, 0)
+    lib().orc_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_),
+                                _fp(G), sums, int(n_threads))
+    return G, np.array(list(sums))
+
+
 def ppo_apply(params, G, adam, cfg):
     """In-place clip + Adam on params (float32 contiguous)."""
     lib().orc_ppo_apply(_fp(params), _fp(G), _fp(adam.m), _fp(adam.v), C.byref(adam.t),

@@ -420,6 +420,31 @@ void orc_advantages(const float *returns, const float *value_preds, int64_t n, f
     for (int64_t i = 0; i < n; ++i) adv[i] = (adv[i] - mean) / (std + 1e-5f);
 }
 
+/* All-cores form of orc_ppo_grad_rows for bench.py's cpu_baseline leg: rows are split into n_threads contiguous
+ * chunks, each chunk accumulates into a private gradient, and the chunks are summed in chunk order (deterministic for a
+ * given n_threads; differs from the single-thread sum only by fp32 summation order). */
+void orc_ppo_grad_rows_mt(const orc_policy_dims *d, const float *P, const orc_ppo_cfg *cfg,
+                          const float *obs, const float *actions, const float *value_preds,
+                          const float *returns, const float *old_logp, const float *adv,
+                          const int64_t *rows, int n_rows, float inv_B, float *G, double *sums, int n_threads) {
+    int64_t n = orc_policy_num_params(d);
+    if (n_threads < 1) n_threads = 1;
+    float *Gt = (float *)calloc((size_t)n_threads * n, sizeof(float));
+    double *St = (double *)calloc((size_t)n_threads * 3, sizeof(double));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; ++t) {
+        int lo = (int)((int64_t)n_rows * t / n_threads), hi = (int)((int64_t)n_rows * (t + 1) / n_threads);
+        orc_ppo_grad_rows(d, P, cfg, obs, actions, value_preds, returns, old_logp, adv, rows + lo, hi - lo, inv_B,
+                          Gt + (size_t)t * n, St + 3 * t);
+    }
+    for (int t = 0; t < n_threads; ++t) {
+        for (int64_t i = 0; i < n; ++i) G[i] += Gt[(size_t)t * n + i];
+        for (int i = 0; i < 3; ++i) sums[i] += St[3 * t + i];
+    }
+    free(Gt);
+    free(St);
+}
+
 /* One optimizer step from an already-summed gradient: clip + Adam.  a2c/algo/ppo.py:143-145 */
 void orc_ppo_apply(float *P, float *G, float *M, float *V, int64_t *t, int64_t n,
                    const orc_ppo_cfg *cfg) {
@@ -558,6 +583,29 @@ void orc_disc_grad_rows(int F, int Hd, const float *P, const float *expert_rows 
         linear_bwd_w(G + L.w1, G + L.b1, z1b, xm, Hd, F);  /* dW1 += z1b xm^T ; db1 += z1b */
     }
     free(buf);
+}
+
+/* All-cores form of orc_disc_grad_rows (bench.py cpu_baseline): row triples split over n_threads, private gradients
+ * summed in chunk order. */
+void orc_disc_grad_rows_mt(int F, int Hd, const float *P, const float *expert_rows, const float *policy_rows,
+                           const float *alpha, int nb, float inv_B, float lambda_, float *G, double *sums, int n_threads) {
+    int64_t n = orc_disc_num_params(F, Hd);
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > nb) n_threads = nb;
+    float *Gt = (float *)calloc((size_t)n_threads * n, sizeof(float));
+    double *St = (double *)calloc((size_t)n_threads * 3, sizeof(double));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; ++t) {
+        int lo = (int)((int64_t)nb * t / n_threads), hi = (int)((int64_t)nb * (t + 1) / n_threads);
+        orc_disc_grad_rows(F, Hd, P, expert_rows + (size_t)lo * F, policy_rows + (size_t)lo * F, alpha + lo, hi - lo, inv_B,
+                           lambda_, Gt + (size_t)t * n, St + 3 * t);
+    }
+    for (int t = 0; t < n_threads; ++t) {
+        for (int64_t i = 0; i < n; ++i) G[i] += Gt[(size_t)t * n + i];
+        for (int i = 0; i < 3; ++i) sums[i] += St[3 * t + i];
+    }
+    free(Gt);
+    free(St);
 }
 
 /* Discriminator.update_gail_dyn a2c/algo/gail.py:154-193.
