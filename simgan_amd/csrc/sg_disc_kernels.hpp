@@ -411,6 +411,18 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
 // Arguments are individual scalars / pointers (14 dwords), not a struct: the code object asks the command
 // processor to preload them into SGPRs (-amdgpu-kernarg-preload-count), so the first global loads do not wait
 // for a kernarg fetch from memory (~1 us after a fresh launch).
+// A wave cannot run ahead of the vector-memory instructions it has issued, and a CU's memory pipe moves ~64 B per clock:
+// a block whose waves each queue all four of their weight slices (190 KB) up front spends ~4k cycles issuing before its
+// first GEMM.  The slices are therefore requested in consumption order with the LAST one (W1^T, first used by the
+// fourth phase) deferred until the first GEMM has been issued, and a bare s_barrier (no counter wait: the loads stay in
+// flight) after the W1 requests keeps the pipe -- which serves the oldest wave first -- from queueing wave 0's later
+// matrices ahead of wave 6's first one.
+#define SG4_ISSUE_FENCE()                      \
+    do {                                       \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
 struct Chain4Args {
     const float *params, *wT;
     float *ops, *part;
@@ -432,9 +444,14 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
     const float* I_W2T = I_W2 + Hp * Hp;
     const float* I_W1T = I_W2T + Hp * Hp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 4, cl = lane & 15;
-    const int col = 16 * wave + cl;
-    const bool actH = wave < KH, actF = wave < KF;
-    const int wvH = actH ? wave : KH - 1, colH = 16 * wvH + cl;
+    // Column-tile ownership is rotated by the block index: the 12 blocks of an XCD would otherwise ask their L2 for the
+    // same weight slices in the same order at the same moment (one hot channel at a time); rotated, wave 0 of
+    // neighbouring blocks starts on different slices.
+    constexpr int NWC_ = KF > KH ? KF : KH;
+    const int tile = (wave + (int)(blockIdx.x >> 3)) % NWC_;
+    const int col = 16 * tile + cl;
+    const bool actH = tile < KH, actF = tile < KF;
+    const int wvH = actH ? tile : KH - 1, colH = 16 * wvH + cl;
     const int nb = 16 * a.G, Kt = 4 * nb, G4 = 4 * a.G;
     const SgStacks stk = sg_disc_stacks(a.ops, Kt, Hp, Fp, ldF);
     float* L2s = stk.L2;
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             sg4_mma<Hp, 1>(ah, w2, lane, o);
             h2 = sg_tanh(o[0] + b2c);
             const float pl = sg4_rowsum16(h2 * w3c);
-            if (cl == 0) LP[wave * 4 + s] = pl;
+            if (cl == 0) LP[tile * 4 + s] = pl;
         }
         SG_PHASE_SYNC(2);
         {   // logit, BCE loss and dL/dd of this lane's row   (a2c/algo/gail.py:168-176)
@@ -543,17 +560,16 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
         __builtin_amdgcn_sched_barrier(0);
         b1c = P[o_b1 + colH]; b2c = P[o_b2 + colH]; w3c = P[o_w3 + colH];
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_sched_barrier(0);
+        SG4_ISSUE_FENCE();
         sg4_load_w<Hp>(w2, I_W2, wvH, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        sg4_load_w<Hp>(w2t, I_W2T, wvH, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        sg4_load_w<Hp>(w1t, I_W1T, wave < KF ? wave : KF - 1, lane);
         __builtin_amdgcn_sched_barrier(0);
         float h1 = 0.f, h2 = 0.f, u1 = 0.f, sb1 = 0.f, gown = 0.f;
         if (actH) {
             float o[1];
             sg4_mma<Fp, 1>(ax, w1, lane, o);
+            __builtin_amdgcn_sched_barrier(0);
+            sg4_load_w<Hp>(w2t, I_W2T, wvH, lane);                         // deferred: first used two phases from here
+            __builtin_amdgcn_sched_barrier(0);
             h1 = sg_tanh(o[0] + b1c);
             H1[s * ldAH + col] = h1;
             R2s[SG_STK(Kt, rowB + s, col)] = h1;
@@ -564,6 +580,9 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             float o[1];
             sg4_load_a<Hp, 1>(av, H1, ldAH, lane);
             sg4_mma<Hp, 1>(av, w2, lane, o);
+            __builtin_amdgcn_sched_barrier(0);
+            sg4_load_w<Hp>(w1t, I_W1T, tile < KF ? tile : KF - 1, lane);   // first used two phases from here
+            __builtin_amdgcn_sched_barrier(0);
             h2 = sg_tanh(o[0] + b2c);
             const float d2 = w3c * (1.f - h2 * h2);
             D2[s * ldAH + col] = d2;

@@ -280,8 +280,68 @@ __global__ __launch_bounds__(512) void k_flag_probe(float* data, int words, int 
     }
 }
 
+// MODE 3: the same hand-off confined to ONE XCD.  8 x (np + nc) blocks are launched; a block reads the XCC id the hardware
+// reports and leaves unless it runs on XCC 0; the survivors draw tickets (producers first).  Producers write with PLAIN stores
+// (the line stays in the XCD's L2), wait for the acknowledgements and set a plain flag; consumers poll and read with
+// L1-bypassing (sc1) loads, which the shared L2 serves: no fabric round trip on either leg.
+__device__ __forceinline__ unsigned sg_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+__global__ __launch_bounds__(512) void k_flag_probe_xcd(float* data, int words, int np, int nc, unsigned* counter, long long* stamps,
+                                                        float* sums) {
+    __shared__ int role;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        role = -1;
+        if (sg_xcc_id() == 0u) role = (int)__hip_atomic_fetch_add(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int b = role;
+    if (b < 0 || b >= np + nc) return;
+    if (b < np) {
+        for (int i = tid; i < words; i += blockDim.x) data[(size_t)b * words + i] = (float)(b + 1);
+        __syncthreads();   // s_waitcnt vmcnt(0): every store of the block has been acknowledged by the L2
+        if (tid == 0) {
+            stamps[2 * b] = wall_clock64();
+            *reinterpret_cast<volatile unsigned*>(counter + 16 + b) = 1u;
+            stamps[2 * b + 1] = wall_clock64();
+        }
+    } else {
+        __shared__ int ok;
+        if (tid < 64) {
+            int spins = 0;
+            bool all = false;
+            while (!all && spins < (1 << 20)) {
+                bool mine = true;
+                for (int j = tid; j < np; j += 64)
+                    mine = mine && __hip_atomic_load(counter + 16 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                all = __all(mine);
+                ++spins;
+            }
+            if (tid == 0) { ok = spins < (1 << 20); stamps[2 * b] = wall_clock64(); }
+        }
+        __syncthreads();
+        float s = 0.f;
+        if (ok)
+            for (int i = tid; i < np * words; i += blockDim.x)
+                s += __hip_atomic_load(data + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s = sg_wave_sum(s);
+        __shared__ float red[8];
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+            sums[b - np] = ok ? t : -1.f;
+            stamps[2 * b + 1] = wall_clock64();
+        }
+    }
+}
+
 extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int words, long long* stamps, float* sums) {
-    SG_REQUIRE(ctx && stamps && sums && np > 0 && nc > 0 && np + nc <= 256 && words > 0, "sg_test_flag_probe: bad argument");
+    SG_REQUIRE(ctx && stamps && sums && np > 0 && nc > 0 && np + nc <= 256 && words > 0 && (mode != 3 || np + nc <= 32), "sg_test_flag_probe: bad argument");
     SG_CHECK(hipSetDevice(ctx->device));
     float *d_data, *d_sums;
     unsigned* d_cnt;
@@ -295,7 +355,8 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int wor
         SG_CHECK(hipMemsetAsync(d_data, 0, sizeof(float) * (size_t)np * words, ctx->stream));
         if (mode == 0) hipLaunchKernelGGL(k_flag_probe<0>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
         else if (mode == 1) hipLaunchKernelGGL(k_flag_probe<1>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
-        else hipLaunchKernelGGL(k_flag_probe<2>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+        else if (mode == 2) hipLaunchKernelGGL(k_flag_probe<2>, dim3(np + nc), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
+        else hipLaunchKernelGGL(k_flag_probe_xcd, dim3(8 * (np + nc)), dim3(512), 0, ctx->stream, d_data, words, np, nc, d_cnt, d_st, d_sums);
     }
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipStreamSynchronize(ctx->stream));

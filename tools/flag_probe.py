@@ -12,7 +12,8 @@ ctx = _lib.Context.default()
 fn = lib.sg_test_flag_probe
 fn.restype = C.c_int
 fn.argtypes = [_lib.H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_float)]
-for mode, np_, nc, words in ((0, 96, 100, 2048), (1, 96, 100, 2048), (2, 96, 100, 2048), (2, 96, 100, 8192), (2, 32, 100, 2048), (0, 1, 8, 256), (1, 1, 8, 256), (2, 1, 8, 256)):
+for mode, np_, nc, words in ((0, 96, 100, 2048), (1, 96, 100, 2048), (2, 96, 100, 2048), (2, 96, 100, 8192), (2, 32, 100, 2048), (0, 1, 8, 256), (1, 1, 8, 256), (2, 1, 8, 256),
+                             (3, 1, 8, 256), (3, 16, 16, 2048), (3, 16, 16, 8192), (3, 24, 8, 8192), (2, 16, 16, 2048), (2, 16, 16, 8192)):
     st = (C.c_longlong * (2 * (np_ + nc)))()
     sums = (C.c_float * nc)()
     _lib.check(fn(ctx.h, mode, np_, nc, words, st, sums))
@@ -20,6 +21,6 @@ for mode, np_, nc, words in ((0, 96, 100, 2048), (1, 96, 100, 2048), (2, 96, 100
     p, c = s[:np_], s[np_:]
     expect = words * sum(range(1, np_ + 1))
     good = all(abs(x - expect) < 1e-3 * expect for x in sums)
-    print(f"mode {mode} ({'fence' if mode == 0 else 'write-through'}): producers {np_} x {words * 4 // 1024} KiB, consumers {nc}: data ok {good}; release fence+atomic {10 * (p[:, 1] - p[:, 0]).max()} ns max "
+    print(f"mode {mode} ({'fence' if mode == 0 else 'one XCD, plain stores + sc1 loads' if mode == 3 else 'write-through'}): producers {np_} x {words * 4 // 1024} KiB, consumers {nc}: data ok {good}; release fence+atomic {10 * (p[:, 1] - p[:, 0]).max()} ns max "
           f"(median {10 * int(np.median(p[:, 1] - p[:, 0]))}); last producer pre-fence -> consumers saw flag {10 * (c[:, 0].min() - p[:, 0].max())}.."
           f"{10 * (c[:, 0].max() - p[:, 0].max())} ns; consumers read-back {10 * int(np.median(c[:, 1] - c[:, 0]))} ns median")

@@ -28,7 +28,7 @@ _lib.check(fn(disc.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 32)
 for name, b in ((("mix block 0", 0), ("mix block 9", 9), ("BCE block", nb // 3 + 5)) if thin else (("BCE block 0", 0), ("mix block", nb // 2))):
     row = t[b]
-    idx = [i for i in range(32) if row[i] != 0 and i not in (28, 29)]
+    idx = sorted([i for i in range(32) if row[i] != 0 and i not in (28, 29)], key=lambda i: row[i])
     print(name, "total cycles", row[idx[-1]] - row[idx[0]])
     for i0, i1 in zip(idx[:-1], idx[1:]):
         print(f"   phase {i0:2d}->{i1:2d}: {row[i1] - row[i0]:8d} cycles")
