@@ -220,17 +220,31 @@ def main():
         ctx.synchronize()
         pg.barrier()
 
-    for _ in range(args.warmup):
-        learner.update()
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = learner.update()
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed = pg.max(elapsed)
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            learner.update()
+        barrier()
+        t0 = time.perf_counter()
+        last_ = None
+        for _ in range(steps):
+            last_ = learner.update()
+        ctx.synchronize()
+        mine = time.perf_counter() - t0
+        barrier()
+        return pg.max(mine), pg.gather(mine), last_
+
+    elapsed, per_rank, last = timed(args.steps, args.warmup)
+    # N > 1: the discriminator has two data-parallel modes.  `value` is the default (replicated:
+    # every rank runs the full-batch steps on the union of the ranks' rows, no per-step collective); the sharded mode
+    # (batch/world rows per rank, one gradient all-reduce per step) is timed as well and reported beside it.
+    alt = None
+    if world > 1 and w["E_d"]:
+        ctx.set_disc_dp(not ctx.disc_sharded)
+        e2, pr2, _ = timed(max(2, args.steps // 2), 2)
+        alt = dict(mode="sharded" if ctx.disc_sharded else "replicated", ms_per_step=round(1e3 * e2 / max(2, args.steps // 2), 3),
+                   value=round(w["T"] * w["N"] * world * max(2, args.steps // 2) / e2, 1),
+                   per_rank_ms_per_step=[round(1e3 * x / max(2, args.steps // 2), 3) for x in pr2])
+        ctx.set_disc_dp(not ctx.disc_sharded)
 
     # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
     ctx.profile_reset()
@@ -285,7 +299,14 @@ def main():
             "us_per_optimizer_step": round(1e3 * ms_per_step / (work["d_steps"] + work["ppo_steps"]), 2),
             "last_losses": last,
             "device": name, "num_cu": num_cu,
+            "per_rank_ms_per_step": [round(1e3 * x / args.steps, 3) for x in per_rank],
         }
+        if world > 1:
+            out["comm"] = {"backend": "RCCL (dlopen) on the library stream, captured into the update's hipGraphs",
+                           "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
+                           "disc_mode": "sharded" if ctx.disc_sharded else "replicated"}
+            if alt:
+                out["comm"]["disc_other_mode"] = alt
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, expert, args.cpu_seconds)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

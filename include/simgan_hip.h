@@ -51,7 +51,12 @@ int sg_ctx_device_info(sg_ctx *ctx, char *name, int name_len, int *num_cu, int64
  * id is the 128-byte ncclUniqueId produced on rank 0 and broadcast by the host launcher. */
 int sg_comm_unique_id(uint8_t id[128]);
 int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
+/* rank / world as the communicator itself reports them (ncclCommUserRank / ncclCommCount) once it exists. */
 int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
+/* Discriminator data-parallel mode for world > 1: 0 = replicated (default: one all-gather of
+ * the ranks' rows per epoch, identical full-batch steps everywhere), 1 = sharded (batch/world rows per rank and one
+ * gradient all-reduce per step).  Initial value: SG_DISC_DP=sharded in the environment. */
+int sg_ctx_set_disc_dp(sg_ctx *ctx, int sharded);
 
 /* ------------------------------------------------------------------- policy */
 enum { SG_POLICY_MLP = 0, SG_POLICY_SPLIT = 1 };

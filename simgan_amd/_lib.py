@@ -44,6 +44,7 @@ PROTOTYPES = {
     "sg_comm_unique_id": (C.c_int, [c_u8_p]),
     "sg_ctx_comm_init": (C.c_int, [H, c_u8_p, C.c_int, C.c_int]),
     "sg_ctx_comm_info": (C.c_int, [H, c_int_p, c_int_p]),
+    "sg_ctx_set_disc_dp": (C.c_int, [H, C.c_int]),
     "sg_policy_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "sg_policy_destroy": (C.c_int, [H]),
     "sg_policy_num_params": (C.c_int, [H, c_i64_p]),
@@ -186,6 +187,16 @@ class Context:
         check(self.lib.sg_ctx_comm_init(self.h, buf, rank, world))
         self.rank, self.world = rank, world
         self.disc_sharded = os.environ.get("SG_DISC_DP", "") == "sharded"   # read by sg_ctx_comm_init as well
+
+    def comm_info(self):
+        """(rank, world) as RCCL's communicator reports them."""
+        r, w = C.c_int(0), C.c_int(0)
+        check(self.lib.sg_ctx_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def set_disc_dp(self, sharded):
+        check(self.lib.sg_ctx_set_disc_dp(self.h, 1 if sharded else 0))
+        self.disc_sharded = bool(sharded)
 
     def profile(self, enable):
         check(self.lib.sg_ctx_profile(self.h, 1 if enable else 0))

@@ -27,6 +27,8 @@ struct SgRccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 
 struct SgComm {
@@ -52,6 +54,8 @@ static int rccl_load() {
     SG_SYM(AllReduce, "ncclAllReduce");
     SG_SYM(AllGather, "ncclAllGather");
     SG_SYM(GetErrorString, "ncclGetErrorString");
+    SG_SYM(CommCount, "ncclCommCount");
+    SG_SYM(CommUserRank, "ncclCommUserRank");
 #undef SG_SYM
     return 0;
 }
@@ -100,6 +104,21 @@ extern "C" int sg_ctx_comm_info(sg_ctx* ctx, int* rank, int* world) {
     SG_REQUIRE(ctx, "sg_ctx_comm_info: ctx is NULL");
     if (rank) *rank = ctx->rank;
     if (world) *world = ctx->world;
+    if (ctx->comm) {   // what the communicator itself reports (ncclCommUserRank / ncclCommCount), not what it was asked for
+        int r = -1, n = -1;
+        SG_NCCL(g_rccl.CommUserRank(ctx->comm->comm, &r));
+        SG_NCCL(g_rccl.CommCount(ctx->comm->comm, &n));
+        SG_REQUIRE(r == ctx->rank && n == ctx->world, "RCCL reports rank %d of %d, the context was initialised as %d of %d", r, n,
+                   ctx->rank, ctx->world);
+        if (rank) *rank = r;
+        if (world) *world = n;
+    }
+    return 0;
+}
+
+extern "C" int sg_ctx_set_disc_dp(sg_ctx* ctx, int sharded) {
+    SG_REQUIRE(ctx, "sg_ctx_set_disc_dp: ctx is NULL");
+    ctx->disc_sharded = sharded != 0;
     return 0;
 }
 

@@ -153,6 +153,7 @@ struct sg_ppo {
     int64_t opt_t = 0;           // completed Adam steps (mirrors SgOptState::t0 on the device)
     uint64_t scratch_key = 0;    // layout the scratch buffers were last cleared for
     hipGraphExec_t steps_graph = nullptr;   // the update's optimizer steps, captured once and replayed
+    bool graph_refused = false;             // a capture with collectives failed once: stay on direct launches
     uint64_t steps_graph_key[16] = {0};
     sg_ctx* ctx;
     sg_policy* policy;
@@ -189,6 +190,7 @@ struct sg_disc {
     int64_t feat_all_cap = 0;
     int64_t opt_t = 0;             // completed Adam steps (mirrors SgOptState::t0 on the device)
     hipGraphExec_t epoch_graph = nullptr;   // one epoch of update steps, captured once and replayed
+    bool graph_refused = false;             // a capture with collectives failed once: stay on direct launches
     uint64_t epoch_graph_key[12] = {0};
     float* d_wT = nullptr;         // weight images W1 | W2 | W2^T | W1^T of k_disc_chain4, maintained by k_disc_wgrad
     float *d_erows = nullptr, *d_prows = nullptr;   // the epoch's expert / policy rows in consumption order
@@ -230,6 +232,26 @@ __device__ __forceinline__ void sg_opt_prepare(SgOptState* st, int t) {
     st->bc2_sqrt2[t & 1] = (float)sqrt(bc2);
 }
 #endif
+
+// Capture `enqueue()` (kernel launches and, with a communicator, RCCL collectives on ctx->stream) into a graph and
+// instantiate it.  RCCL supports stream capture, but whether a given build / topology accepts it is only known at run
+// time: any failure ends the capture, clears the error and returns 1 ("run it eagerly instead"); 0 = *exec is ready.
+template <typename F>
+static inline int sg_try_capture(sg_ctx* ctx, hipGraphExec_t* exec, F&& enqueue) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    const int rc = enqueue();
+    const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != 0 || ce != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        return 1;
+    }
+    const hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; return 1; }
+    return 0;
+}
 
 // RCCL (sg_comm.cpp)
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n);

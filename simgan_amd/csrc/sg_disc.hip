@@ -493,29 +493,30 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, a.st, n_d);
         return 0;
     };
+    // Sharded mode has one RCCL all-reduce per step inside the sequence: captured with it (see sg_ppo_update), unless
+    // SG_DISC_GRAPH_COMM=0 or the RCCL build refuses the capture.
     const char* genv = getenv("SG_DISC_GRAPH");
-    const bool use_graph = !sharded && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
-    if (!use_graph) {
-        SG_TRY(enqueue_epoch());
-    } else {
+    const char* gcenv = getenv("SG_DISC_GRAPH_COMM");
+    const bool comm_ok = !sharded || (!d->graph_refused && !(gcenv && !strcmp(gcenv, "0")));
+    bool use_graph = comm_ok && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
+    if (use_graph) {
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
-                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin, (uint64_t)ops_f,
+                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin | (sharded ? 2u : 0u), (uint64_t)ops_f,
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
-            hipGraph_t graph = nullptr;
-            SG_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_epoch();
-            const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-            SG_REQUIRE(rc == 0, "sg_disc_update_gail_dyn: launch failed during graph capture");
-            SG_CHECK(ce);
-            SG_CHECK(hipGraphInstantiate(&d->epoch_graph, graph, nullptr, nullptr, 0));
-            SG_CHECK(hipGraphDestroy(graph));
-            memcpy(d->epoch_graph_key, key, sizeof key);
+            if (sg_try_capture(ctx, &d->epoch_graph, enqueue_epoch) != 0) {
+                SG_REQUIRE(sharded, "sg_disc_update_gail_dyn: graph capture of the epoch failed");
+                d->graph_refused = true;
+                use_graph = false;
+            } else {
+                memcpy(d->epoch_graph_key, key, sizeof key);
+            }
         }
-        SG_CHECK(hipGraphLaunch(d->epoch_graph, ctx->stream));
+        if (use_graph) SG_CHECK(hipGraphLaunch(d->epoch_graph, ctx->stream));
     }
+    if (!use_graph) SG_TRY(enqueue_epoch());
     SG_CHECK(hipGetLastError());
     const auto t_enq1 = std::chrono::steady_clock::now();
     double acc[3];

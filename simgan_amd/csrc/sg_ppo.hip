@@ -236,9 +236,11 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
             SG_TRY(sg_fill_perm(ctx, a->d_perms + (size_t)e * TN, TN, seed, (uint64_t)e * 2654435761ull + (uint64_t)ctx->rank));
     }
 
-    // launch geometry: 16-row groups (more workgroups in flight per CU hide the phases' latencies) while the
-    // per-row-group gradient slabs the reduction has to stream stay small (<= 24 MB), else 32-row groups
-    int MT = (size_t)((mb + 15) / 16) * (size_t)(d.total + 8) * sizeof(float) > ((size_t)24 << 20) ? 2 : 1;
+    // launch geometry: 32-row groups as long as they still give every CU a workgroup (half the gradient slabs for
+    // k_ppo_reduce to stream: -1.8 us per step at the north-star shape against +0.6 us in k_ppo_bwd), or when the
+    // 16-row slabs would exceed 24 MB; otherwise 16-row groups (more workgroups in flight hide the phases' latencies)
+    int MT = ((size_t)((mb + 15) / 16) * (size_t)(d.total + 8) * sizeof(float) > ((size_t)24 << 20) ||
+              ((mb + 31) / 32) * d.n_trunks >= ctx->num_cu) ? 2 : 1;
     if (const char* e = getenv("SG_PPO_ROWS")) {   // tuning knob
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) MT = v / 16;
@@ -338,11 +340,14 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, st, E * M);
         return 0;
     };
+    // With a communicator the RCCL all-reduces are part of the captured sequence (RCCL enqueues them on the capturing
+    // stream like any kernel), so N > 1 keeps the one-call-per-update property; SG_PPO_GRAPH_COMM=0 or a capture the
+    // RCCL build refuses falls back to direct launches.
     const char* genv = getenv("SG_PPO_GRAPH");
-    const bool use_graph = !ctx->use_comm && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
-    if (!use_graph) {
-        SG_TRY(enqueue_steps());
-    } else {
+    const char* gcenv = getenv("SG_PPO_GRAPH_COMM");
+    const bool comm_ok = !ctx->use_comm || (!a->graph_refused && !(gcenv && !strcmp(gcenv, "0")));
+    bool use_graph = comm_ok && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
+    if (use_graph) {
         uint32_t fbits[6];
         const float fv[6] = {a->cfg.clip_param, a->cfg.value_loss_coef, a->cfg.entropy_coef, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B};
         memcpy(fbits, fv, sizeof fbits);
@@ -352,21 +357,20 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
-            hipGraph_t graph = nullptr;
-            SG_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_steps();
-            const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-            SG_REQUIRE(rc == 0, "sg_ppo_update: launch failed during graph capture");
-            SG_CHECK(ce);
-            SG_CHECK(hipGraphInstantiate(&a->steps_graph, graph, nullptr, nullptr, 0));
-            SG_CHECK(hipGraphDestroy(graph));
-            memcpy(a->steps_graph_key, key, sizeof key);
+            if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
+                SG_REQUIRE(ctx->use_comm, "sg_ppo_update: graph capture of the optimizer steps failed");
+                a->graph_refused = true;   // RCCL would not be captured here: direct launches from now on
+                use_graph = false;
+            } else {
+                memcpy(a->steps_graph_key, key, sizeof key);
+            }
         }
-        SG_CHECK(hipGraphLaunch(a->steps_graph, ctx->stream));
+        if (use_graph) SG_CHECK(hipGraphLaunch(a->steps_graph, ctx->stream));
     }
+    if (!use_graph) SG_TRY(enqueue_steps());
     SG_CHECK(hipGetLastError());
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));

@@ -365,3 +365,12 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int wor
     (void)hipFree(d_data); (void)hipFree(d_sums); (void)hipFree(d_cnt); (void)hipFree(d_st);
     return 0;
 }
+
+// Test hook: how the last update of each object was issued -- 0 direct launches, 1 replayed graph, 2 a capture was
+// refused once and the object fell back to direct launches (tests/test_gpu_comm.py).
+extern "C" int sg_test_graph_state(sg_ppo* a, sg_disc* d, int out[2]) {
+    SG_REQUIRE(out, "sg_test_graph_state: NULL argument");
+    out[0] = a ? (a->graph_refused ? 2 : (a->steps_graph ? 1 : 0)) : -1;
+    out[1] = d ? (d->graph_refused ? 2 : (d->epoch_graph ? 1 : 0)) : -1;
+    return 0;
+}

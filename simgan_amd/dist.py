@@ -49,6 +49,14 @@ class ProcessGroup(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, value):
+        """One float per rank -> the list of all ranks' values (on every rank)."""
+        if self.dist is None:
+            return [float(value)]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, float(value))
+        return box
+
     def init_device_comm(self, ctx, make_unique_id):
         """Create the RCCL communicator on `ctx`: rank 0 draws the id, everyone joins."""
         if self.world == 1:

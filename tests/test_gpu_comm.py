@@ -58,3 +58,61 @@ def test_rccl_path_single_rank(disc_mode):
     env = dict(os.environ, SG_COMM_ALWAYS="1", SG_DISC_DP=disc_mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "COMM-PATH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+GRAPH_CHILD = r'''
+import ctypes as C, json, os, sys
+import numpy as np
+import simgan_amd as sg
+from simgan_amd import _lib
+
+class Box:
+    def __init__(self, shape): self.shape = tuple(shape)
+class Loader:
+    def __init__(self, expert, batch_size): self.expert, self.batch_size = expert, batch_size
+
+ctx = _lib.Context.default()
+ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+assert ctx.comm_info() == (0, 1)                     # as RCCL itself reports it
+lib = _lib.load()
+T, N, O, A, F = 16, 64, 47, 12, 86
+pol = sg.Policy((O,), Box((A,)), base_kwargs={"recurrent": False, "hidden_size": 64}, seed=1)
+disc = sg.algo.gail.Discriminator(F, 100, None, seed=2)
+agent = sg.algo.PPO(pol, 0.2, 3, 4, 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+agent.seed, disc.seed = 5, 6
+ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F)
+ro.device_resident = True
+_lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 7, 0.02))
+_lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, 0.99, 0.95, 1))
+expert = np.random.default_rng(0).standard_normal((640, F)).astype(np.float32)
+out = []
+for _ in range(2):                                    # second round replays the instantiated graphs
+    out.append(disc.update_gail_dyn(Loader(expert, 128), ro))
+    out.append(agent.update(ro))
+fn = lib.sg_test_graph_state
+fn.restype = C.c_int
+fn.argtypes = [_lib.H, _lib.H, C.POINTER(C.c_int)]
+st = (C.c_int * 2)()
+_lib.check(fn(agent.h, disc.h, st))
+np.savez(sys.argv[1], losses=np.array(out, np.float64), pi=pol.get_flat_params(), d=disc.get_flat_params(), state=np.array(list(st)))
+print("GRAPH-CHILD-OK")
+'''
+
+
+@pytest.mark.parametrize("disc_mode", ["replicated", "sharded"])
+def test_collectives_inside_the_graphs_equal_direct_launches(disc_mode, tmp_path):
+    """With a communicator the RCCL all-reduces are captured into the PPO graph (and, in sharded mode, into the
+    discriminator epoch graph).  One rank, SG_COMM_ALWAYS=1: the captured path must be taken and must give results
+    bit-identical to issuing the same kernels and collectives directly."""
+    import numpy as np
+    res = {}
+    for tag, extra in (("graph", {}), ("direct", {"SG_PPO_GRAPH_COMM": "0", "SG_DISC_GRAPH_COMM": "0"})):
+        env = dict(os.environ, SG_COMM_ALWAYS="1", SG_DISC_DP=disc_mode, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **extra)
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", GRAPH_CHILD, out], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "GRAPH-CHILD-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+        res[tag] = np.load(out)
+    g, e = res["graph"], res["direct"]
+    assert list(g["state"]) == [1, 1 if disc_mode == "sharded" else 1], list(g["state"])   # both replayed graphs
+    assert list(e["state"]) == [0, 0 if disc_mode == "sharded" else 1], list(e["state"])   # replicated D has no per-step collective
+    assert np.array_equal(g["losses"], e["losses"]) and np.array_equal(g["pi"], e["pi"]) and np.array_equal(g["d"], e["d"])
