@@ -22,6 +22,9 @@ db=$(run_prof write --pmc WRITE_SIZE --kernel-trace)
 python $root/tools/rocpd_pmc.py $db > $out/${tag}_pmc_write_size.txt
 cd $root
 timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+for w in hopper laikago refine; do   # the other BASELINE.json configurations (DESIGN.md section 5 quotes these files)
+    timeout 600 python bench.py --workload $w --cpu-seconds 8 > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err
+done
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_pytest_gpu.txt
 rm -f $out/${tag}_*_bench_under_profiler.json
 tail -3 $out/${tag}_pytest_gpu.txt
