@@ -97,6 +97,13 @@ extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, in
     ctx->use_comm = world > 1 || (always && always[0] == '1');
     const char* dp = getenv("SG_DISC_DP");
     ctx->disc_sharded = dp && strcmp(dp, "sharded") == 0;
+    // One tiny all-reduce now: RCCL sets up its channels and proxy connections lazily on the first collective, which must
+    // not happen inside a stream capture (the updates capture their collectives into hipGraphs).
+    float* warm = nullptr;
+    SG_TRY(sg_ctx_scratch(ctx, 64, &warm));
+    SG_CHECK(hipMemsetAsync(warm, 0, 64, ctx->stream));
+    SG_NCCL(g_rccl.AllReduce(warm, warm, 4, ncclFloat32, ncclSum, c->comm, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
