@@ -15,9 +15,12 @@ elementwise.  The POLICY trajectory is not: 160 clipped-surrogate Adam steps amp
 ~3e-4 absolute on individual weights (~1 % of the update's L2 length) -- measured with the oracle against itself,
 tools/trajectory_sensitivity.py -- because rows on a clip / min / max boundary flip branch and Adam turns a flipped
 near-zero gradient into a full lr-sized step.  No two float32 implementations (the reference under two BLAS builds
-included) can agree elementwise beyond that, so the post-update policy is checked as a trajectory: relative L2 distance
-<= 3 % of the update's length and worst entry <= 1e-3, with the measured values printed; the oracle's policy state is
-then re-seeded from the device so the second update is compared from an identical start."""
+included) can agree elementwise beyond that (SplitPolicy, with its state-dependent log-std: 4.3 % / 5.0e-4 under a 1e-5
+perturbation, `tools/trajectory_sensitivity.py hopper`), so the post-update policy is checked as a trajectory: relative L2
+distance <= 10 % of the update's length (about twice the measured float32 floor) and worst entry <= 2e-3, with the measured
+values printed; the oracle's policy state is then re-seeded from the device so the second update is compared from an
+identical start.  The same holds for the action loss, a near-zero mean of +-advantage x ratio terms (-0.003 .. -0.05): it is
+compared at 1e-4 relative plus 5e-5 absolute (self-sensitivity 1e-5 absolute)."""
 import ctypes as C
 import time
 
@@ -33,14 +36,19 @@ def _flat2(a):
     return a.numpy()[..., 0] if hasattr(a, "numpy") else np.asarray(a)[..., 0]
 
 
-def test_bench_path_two_updates_vs_oracle():
+@pytest.mark.parametrize("workload", ["northstar", "hopper"])
+def test_bench_path_two_updates_vs_oracle(workload):
+    """northstar: BASELINE.json's synthetic measurement shape (Policy h64, 2,560 + 160 steps per update); hopper:
+    configs[1] as shipped (HopperCombinedEnv-v1 shapes, SplitPolicy h100 with state-dependent log-std, 256 envs: 1,280 + 160
+    steps per update)."""
     import bench
     import simgan_amd as sg
     from oracle import oracle as orc
     from simgan_amd import _lib
 
-    w = bench.WORKLOADS["northstar"]
+    w = bench.WORKLOADS[workload]
     T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
+    n_d_expected = min(w["Ne"] // B, T * N // B)
     pol, disc, agent, ro, loader, expert, learner = bench.build_problem(sg, w, seed=0)
     lib = _lib.load()
     _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
@@ -57,7 +65,7 @@ def test_bench_path_two_updates_vs_oracle():
 
     disc.update_gail_dyn = recording_update
 
-    d = orc.dims(orc.KIND_MLP, O, A, H, 1)
+    d = orc.dims(orc.KIND_MLP if w["kind"] == "mlp" else orc.KIND_SPLIT, O, A, H, w["feet"])
     pi, dp = pol.get_flat_params(), disc.get_flat_params()
     pi_adam, d_adam = orc.AdamState(pi.size), orc.AdamState(dp.size)
     cfg = orc.ppo_cfg(w["clip"], w["E_p"], w["M"], 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
@@ -74,7 +82,7 @@ def test_bench_path_two_updates_vs_oracle():
         assert len(draws) == w["E_d"] and perms.shape == (w["E_p"], T * N)
         for ep_, pp_, al_ in draws:                 # the library's own draws are what the reference's would be: bijections, U[0,1)
             assert np.array_equal(np.sort(ep_), np.arange(w["Ne"])) and np.array_equal(np.sort(pp_), np.arange(T * N))
-            assert al_.size == 512 * B and al_.min() >= 0.0 and al_.max() < 1.0
+            assert al_.size == n_d_expected * B and al_.min() >= 0.0 and al_.max() < 1.0
         assert len({a_[0][:64].tobytes() for a_ in draws}) == w["E_d"], "every epoch must draw a fresh permutation"
 
         # ---- the same update through the oracle (a2c/main_gail_dyn_ppo.py:255-304)
@@ -82,7 +90,7 @@ def test_bench_path_two_updates_vs_oracle():
         t0 = time.perf_counter()
         for k, (ep_, pp_, al_) in enumerate(draws):
             dl, n_d = orc.disc_update(F, Hd, dp, d_adam, expert, obs_feat, B, ep_, pp_, al_)
-            assert n_d == 512
+            assert n_d == n_d_expected
         r_sa = orc.alive_bonus(masks, T, N, 500.0)
         rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, bench.GAMMA, -r_sa, d_ret, rms)
         nv = orc.policy_forward(d, pi, obs[T])[0][:, 0]
@@ -100,7 +108,7 @@ def test_bench_path_two_updates_vs_oracle():
         assert_close(_flat2(ro.value_preds)[T], nv, what=tag + "value_preds[T] = get_value(obs[T])")
         assert_close(_flat2(ro.returns)[:T], ret[:T], rtol=2e-4, atol=2e-4, what=tag + "GAE returns")
         assert_close([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl, what=tag + "D losses of the last epoch")
-        assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], pl, rtol=1e-4, atol=2e-5, what=tag + "PPO losses")
+        assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], pl, rtol=1e-4, atol=5e-5, what=tag + "PPO losses")
         # trajectory level: 2,560 (D) / 160 (pi) Adam steps from identical starts.  Steps are lr-sized (1e-3 / 3e-4), so
         # a parameter that moved ~0.1-1 carries the accumulated fp32 reordering noise of every step: 1e-4 relative on the
         # weights' own scale + a 2e-4 absolute floor for the entries near zero.
@@ -112,9 +120,9 @@ def test_bench_path_two_updates_vs_oracle():
         worst = np.abs(p_hip - pi).max()
         frac = float(np.mean(np.abs(p_hip - pi) > 5e-5 + 1e-4 * np.abs(pi)))
         print(f"{tag}policy after 160 steps: rel L2 of the update {rel_l2:.2e}, worst entry {worst:.2e}, "
-              f"{100 * frac:.1f} % of entries beyond 1e-4 rel (float32 self-sensitivity: 1.2e-02, 2.8e-04, 17.5 %)")
-        assert rel_l2 <= 3e-2 and worst <= 1e-3, (rel_l2, worst)
-        assert move > 0.3, "the update must move the policy far more than the tolerance"
+              f"{100 * frac:.1f} % of entries beyond 1e-4 rel (float32 self-sensitivity: MLP 1.2e-02 / 2.8e-04 / 17.5 %, split 4.3e-02 / 5.0e-04 / 39 %)")
+        assert rel_l2 <= 1e-1 and worst <= 2e-3, (rel_l2, worst)
+        assert move > 0.2, "the update must move the policy far more than the tolerance"
 
         # ---- device after_update / count_dones against numpy on the downloaded buffers
         for name in ("obs", "obs_feat", "masks", "bad_masks"):
