@@ -377,13 +377,16 @@ __device__ __forceinline__ void sg_grad_tn(const float* dY, int ldy, const float
     sg_grad_tn2<KC>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
 }
 
-// g[c] (+)= sum_{r<R} M[r][c]  for c < Np  (bias gradients), one thread per column.
+// g[c] (+)= sum_{r<R} M[r][c]  for c < Np  (bias gradients).  16 lanes per column (one DPP row), each summing every
+// 16th row with independent LDS reads, then a row reduction: a column costs R/16 reads of latency instead of R.
 __device__ __forceinline__ void sg_colsum(const float* M, int ldm, int R, int Np, float* g,
                                           bool accumulate) {
-    for (int c = threadIdx.x; c < Np; c += blockDim.x) {
+    const int sub = threadIdx.x & 15;
+    for (int c = threadIdx.x >> 4; c < Np; c += blockDim.x >> 4) {
         float s = 0.f;
-        for (int r = 0; r < R; ++r) s += M[r * ldm + c];
-        g[c] = accumulate ? g[c] + s : s;
+        for (int r = sub; r < R; r += 16) s += M[r * ldm + c];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        if (sub == 0) g[c] = accumulate ? g[c] + s : s;
     }
 }
 

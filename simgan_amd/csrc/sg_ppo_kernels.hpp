@@ -239,18 +239,23 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
+    SG_PPO_STAMP(0);
     sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
     __syncthreads();
+    SG_PPO_STAMP(1);
     if (FUSED) {   // forward on this row group (a2c/model.py:255-264, a2c/distributions.py:109-118), activations stay in LDS
         const float* b1 = W + tr.b1;
         const float* b2 = W + tr.b2;
         const float* bh = W + tr.bh;
         sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         __syncthreads();
+        SG_PPO_STAMP(2);
         sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
+        SG_PPO_STAMP(3);
         sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
         __syncthreads();
+        SG_PPO_STAMP(4);
     }
     SG_PPO_STAMP(9);
 
@@ -280,54 +285,69 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
             ROWL[r] = lv;
         }
     } else {
-        // 32 lanes per row, one action dimension per lane; log-prob / entropy summed across the row's
-        // lanes with shuffles, every lane then forms its own d/dmean, d/dlogstd
+        // Gaussian log-prob / entropy of every row and d(loss)/d(mean, log-std).  All R rows in ONE pass: a row gets
+        // L = blockDim / R lanes (16, 8 or 4), a lane takes action dimensions sub, sub + L, ... (at most 8 of them: A <= 8 L
+        // for every shipped policy); sigma and diff are computed once and kept in registers across the row reduction.
+        // (Round 1 gave a row 32 lanes and walked the rows in R/8 passes: four dependent expf / logf / expf chains per
+        // workgroup at 32-row groups, 6.4k of the block's 31k cycles.)
         const SgTrunk tra = d.trunk[0];
+        const int L = blockDim.x / R;
+        if (A <= 8 * L) {
+            const int r = tid / L, sub = tid - r * L;
+            float* o0 = O0 + r * ldP;
+            float* o1 = O1 + r * ldP;
+            float sig[8], dif[8];
+            float* pmv[8];
+            float* plv[8];
+            float lp = 0.f, en = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = sub + j * L;
+                sig[j] = 1.f; dif[j] = 0.f; pmv[j] = nullptr; plv[j] = nullptr;
+                if (k < A) {
+                    float mean, ls;
+                    if (mlp) { pmv[j] = o0 + k; plv[j] = o1 + k; mean = *pmv[j]; ls = W[tra.ex + k]; }
+                    else if (k < d.nc) { pmv[j] = o0 + k; plv[j] = o0 + d.nc + k; mean = *pmv[j]; ls = *plv[j]; }
+                    else { pmv[j] = o1 + (k - d.nc); plv[j] = o1 + (d.na + k - d.nc); mean = *pmv[j]; ls = *plv[j]; }
+                    sig[j] = expf(ls);
+                    dif[j] = ACT[r * A + k] - mean;
+                    const float lsig = logf(sig[j]);
+                    lp += -(dif[j] * dif[j]) / (2.f * sig[j] * sig[j]) - lsig - HALF_LOG_2PI;
+                    en += 0.5f + HALF_LOG_2PI + lsig;
+                }
+            }
+            for (int o = 1; o < L; o <<= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); }
+            const float logp = lp, ent = en;
+            const bool valid = VALID[r];
+            float dlogp = 0.f, la = 0.f;
+            if (valid) {
+                const float adv = SC[1 * R + r];
+                const float ratio = expf(logp - SC[0 * R + r]);
+                const float surr1 = ratio * adv;
+                const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
+                const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);  // torch.min tie -> 1/2, 1/2
+                const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
+                dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
+                la = -fminf(surr1, surr2);
+            }
+            const float dent = valid ? a.ecoef * a.inv_B : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = sub + j * L;
+                if (k < A) {
+                    const float var = sig[j] * sig[j];
+                    *pmv[j] = dlogp * dif[j] / var;
+                    *plv[j] = dlogp * (dif[j] * dif[j] / var - 1.f) - dent;
+                } else if (mlp && k < tra.Pp) {
+                    o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
+                }
+            }
+            if (sub == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
+        } else {
         const int rows_per_pass = blockDim.x >> 5;
         for (int r = tid >> 5; r < R; r += rows_per_pass) {
             float* o0 = O0 + r * ldP;
             float* o1 = O1 + r * ldP;
-            if (A <= 32) {
-                // one action dimension per lane (every shipped policy): sigma, diff are computed once and kept
-                const int k = tid & 31;
-                float mean = 0.f, ls = 0.f, sigma = 1.f, diff = 0.f, lp = 0.f, en = 0.f;
-                float *pm = nullptr, *pl = nullptr;
-                if (k < A) {
-                    if (mlp) { pm = o0 + k; pl = o1 + k; mean = *pm; ls = W[tra.ex + k]; }
-                    else if (k < d.nc) { pm = o0 + k; pl = o0 + d.nc + k; mean = *pm; ls = *pl; }
-                    else { pm = o1 + (k - d.nc); pl = o1 + (d.na + k - d.nc); mean = *pm; ls = *pl; }
-                    sigma = expf(ls);
-                    diff = ACT[r * A + k] - mean;
-                    const float lsig = logf(sigma);
-                    lp = -(diff * diff) / (2.f * sigma * sigma) - lsig - HALF_LOG_2PI;
-                    en = 0.5f + HALF_LOG_2PI + lsig;
-                }
-                // 32 lanes = two 16-lane DPP rows: row sums on the VALU, then one cross-row exchange
-                lp = sg4_rowsum16(lp); en = sg4_rowsum16(en);
-                const float logp = lp + __shfl_xor(lp, 16), ent = en + __shfl_xor(en, 16);
-                const bool valid = VALID[r];
-                float dlogp = 0.f, la = 0.f;
-                if (valid) {
-                    const float adv = SC[1 * R + r];
-                    const float ratio = expf(logp - SC[0 * R + r]);
-                    const float surr1 = ratio * adv;
-                    const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
-                    const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);  // torch.min tie -> 1/2, 1/2
-                    const float inr = (ratio >= 1.f - a.clip && ratio <= 1.f + a.clip) ? 1.f : 0.f;
-                    dlogp = -a.inv_B * (w1 * adv + (1.f - w1) * adv * inr) * ratio;
-                    la = -fminf(surr1, surr2);
-                }
-                const float dent = valid ? a.ecoef * a.inv_B : 0.f;
-                if (k < A) {
-                    const float var = sigma * sigma;
-                    *pm = dlogp * diff / var;
-                    *pl = dlogp * (diff * diff / var - 1.f) - dent;
-                } else if (mlp && k < tra.Pp) {
-                    o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
-                }
-                if (k == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
-                continue;
-            }
             float logp = 0.f, ent = 0.f;
             for (int k0 = 0; k0 < A; k0 += 32) {
                 const int k = k0 + (tid & 31);
@@ -374,6 +394,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
                 }
             }
             if ((tid & 31) == 0) { ROWL[r] = la; ROWL[R + r] = valid ? ent : 0.f; }
+        }
         }
     }
     __syncthreads();

@@ -26,11 +26,15 @@ nb = 1024
 buf = (C.c_longlong * (16 * nb))()
 _lib.check(fn(agent.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 16)
-names = ["issue+rows", "commit+sync", "L1", "L2", "head"]
+names = ["rows->LDS (fused bwd: until the weight commit)", "commit+sync", "L1", "L2", "head"]
 t1 = t[512:]
 t = t[:256]
+t = t[t[:, 8] > 0]          # row groups that exist at this launch geometry (16- or 32-row groups)
+if t[:, 5].max() == 0:      # fused backward: stamps 0..4 sit inside its forward recomputation, measured from stamp 8
+    t[:, 5] = t[:, 4]
+    t[:, 0:5] = np.concatenate([t[:, 8:9], t[:, 0:4]], axis=1)
 d = np.diff(t[:, :6], axis=1)
-print("k_ppo_fwd phases, median cycles over", nb, "row groups:")
+print("k_ppo_fwd phases (or the fused backward's head), median cycles over", nb, "row groups:")
 for i, n in enumerate(names):
     print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
 print("   total       ", int(np.median(t[:, 5] - t[:, 0])))
