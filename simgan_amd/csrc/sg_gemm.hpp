@@ -295,6 +295,31 @@ __device__ __forceinline__ void sg_layer_nn(const float* dY, int ldy, const floa
     });
 }
 
+// Unit-distributed forms: a task is ONE 16x16 output tile (row tile i, column tile tn), dealt round-robin to the waves.
+// With 8 waves and 32 rows x 64 columns every wave gets one tile (half the MFMA chain of the column-strip forms above).
+template <int MT, typename EP>
+__device__ __forceinline__ void sg_layer_nt_u(const float* in, int ldi, const float* W, int ldw, int K, int Np, EP&& ep) {
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, ntl = Np >> 4;
+    for (int u = wave; u < MT * ntl; u += nw) {
+        const int i = u / ntl, tn = u - i * ntl;
+        f32x4 acc[1][1];
+        sg_acc_zero(acc);
+        sg_mma_nt<1, 1>(in + i * 16 * ldi, ldi, W + tn * 16 * ldw, ldw, K, acc);
+        sg_tile_foreach(acc[0][0], i * 16, tn * 16, ep);
+    }
+}
+template <int MT, typename EP>
+__device__ __forceinline__ void sg_layer_nn_u(const float* dY, int ldy, const float* W, int ldw, int K, int Np, EP&& ep) {
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, ntl = Np >> 4;
+    for (int u = wave; u < MT * ntl; u += nw) {
+        const int i = u / ntl, tn = u - i * ntl;
+        f32x4 acc[1][1];
+        sg_acc_zero(acc);
+        sg_mma_nn<1, 1>(dY + i * 16 * ldy, ldy, W + tn * 16, ldw, K, acc);
+        sg_tile_foreach(acc[0][0], i * 16, tn * 16, ep);
+    }
+}
+
 // ---- weight gradient ("TN"):  G[m][n] (+)= sum_{r<R} dY[r][m] X[r][n]  (+ sum_r dY2[r][m] X2[r][n])
 // written to global memory.  Each wave owns whole 16-row panels of G: it reads its A fragment
 // (16 columns of dY) once, all B fragments of up to 8 column tiles, issues every LDS read before
@@ -342,21 +367,27 @@ __device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, i
         }
 }
 
-template <int KC>
+// NW_HINT: the number of waves the caller launches with when that is more than 4 (a compile-time hint, so that with
+// compile-time Mp / Np the strip width and the panel switch below still fold to one case; 0 = 8-tile strips).
+template <int KC, int NW_HINT = 0>
 __device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const float* X, int ldx,
                                             const float* dY2, const float* X2, int Mp, int Np,
                                             float* G, int ldg, bool accumulate) {
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-    const int tm_n = Mp >> 4, tn_n = Np >> 4, blocks_n = (tn_n + 7) >> 3;
+    // column tiles per wave-task: 8 (one A fragment feeds the whole strip), narrower when that would leave waves idle
+    const int tm_n = Mp >> 4, tn_n = Np >> 4;
+    int bw = 8;
+    if (NW_HINT > 4) while (bw > 1 && tm_n * ((tn_n + bw - 1) / bw) < NW_HINT) bw >>= 1;   // (no gain for 4-wave workgroups, measured)
+    const int blocks_n = (tn_n + bw - 1) / bw;
     for (int t = wave; t < tm_n * blocks_n; t += nw) {
         const int tm = t / blocks_n, tb = t % blocks_n;
-        const int ntn = tn_n - 8 * tb < 8 ? tn_n - 8 * tb : 8;
+        const int ntn = tn_n - bw * tb < bw ? tn_n - bw * tb : bw;
         const float* ap = dY + (4 * lq) * ldy + tm * 16 + li;
-        const float* bp = X + (4 * lq) * ldx + tb * 128 + li;
+        const float* bp = X + (4 * lq) * ldx + tb * bw * 16 + li;
         const float* ap2 = dY2 ? dY2 + (4 * lq) * ldy + tm * 16 + li : ap;
-        const float* bp2 = X2 ? X2 + (4 * lq) * ldx + tb * 128 + li : bp;
-        float* g = G + (size_t)(tm * 16) * ldg + tb * 128;
+        const float* bp2 = X2 ? X2 + (4 * lq) * ldx + tb * bw * 16 + li : bp;
+        float* g = G + (size_t)(tm * 16) * ldg + tb * bw * 16;
 #define SG_PANEL(N)                                                                              \
     do {                                                                                         \
         if (dY2) sg_tn_panel<KC, N, true>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);       \
@@ -371,10 +402,24 @@ __device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const floa
     }
 }
 
-template <int KC>
+template <int KC, int NW_HINT = 0>
 __device__ __forceinline__ void sg_grad_tn(const float* dY, int ldy, const float* X, int ldx, int Mp,
                                            int Np, float* G, int ldg, bool accumulate) {
-    sg_grad_tn2<KC>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
+    sg_grad_tn2<KC, NW_HINT>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
+}
+
+// sum over the 16 lanes of one DPP row, result in all 16 lanes: quad butterflies, then the half-row and row mirrors
+// (every lane of a quad already holds the quad's sum) -- four VALU instructions, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float sg_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sg_rowsum16(float v) {
+    v = sg_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = sg_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = sg_dpp_add<0x141>(v);   // row_half_mirror
+    v = sg_dpp_add<0x140>(v);   // row_mirror
+    return v;
 }
 
 // g[c] (+)= sum_{r<R} M[r][c]  for c < Np  (bias gradients).  16 lanes per column (one DPP row), each summing every
@@ -385,7 +430,7 @@ __device__ __forceinline__ void sg_colsum(const float* M, int ldm, int R, int Np
     for (int c = threadIdx.x >> 4; c < Np; c += blockDim.x >> 4) {
         float s = 0.f;
         for (int r = sub; r < R; r += 16) s += M[r * ldm + c];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        s = sg_rowsum16(s);
         if (sub == 0) g[c] = accumulate ? g[c] + s : s;
     }
 }

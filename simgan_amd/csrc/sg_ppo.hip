@@ -83,8 +83,10 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
 }
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
-    const dim3 block(256);
+    dim3 block(256);
     if (fused) {   // Policy (independent actor / critic trunks): forward recomputed inside, no k_ppo_fwd launch
+        const char* we = getenv("SG_PPO_WAVES");   // tuning knob: 4 or 8 waves per workgroup
+        if (!(we && atoi(we) == 4)) block = dim3(MT >= 2 ? 512 : 256);   // 8 waves once a workgroup has two row tiles to deal out
         if (MT == 1 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true>), grid, block, lds, pa);

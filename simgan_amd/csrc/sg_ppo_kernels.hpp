@@ -47,6 +47,11 @@ struct PpoArgs {
     int k1, G;            // 1-based step index within the update; row groups (k_ppo_bwd: blockIdx.x == 0 is the spare block)
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): in the backward phases that is
+// the acknowledgement of the gradient-slab stores the phase has just issued -- a memory round trip per phase for data no
+// later phase of the kernel reads.
+#define SG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 #define SG_PPO_STAMP(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[blockIdx.x * 16 + (n)] = clock64(); } while (0)
 #define SG_PPO_WALL(n) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y < 2) a.dbg[(blockIdx.x + 512 * blockIdx.y) * 16 + (n)] = wall_clock64(); } while (0)
 
@@ -153,8 +158,12 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
 // FUSED (Policy: the actor and critic trunks do not depend on each other's outputs): the workgroup stages the
 // whole trunk, recomputes the forward on its own rows in LDS and goes straight on to the loss -- no k_ppo_fwd
 // launch, no activation stacks written, flushed and read back (5 MB per step at the north-star shape).
+// The fused form runs with 8 waves (512 threads) when the launch code asks for it: the layer GEMMs are then dealt out per
+// 16x16 output tile (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per
+// SIMD hide each other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights
+// staged once and one slab per 32 rows.
 template <int MT, int KO, int KH, bool FUSED = false>
-__global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
+__global__ __launch_bounds__(FUSED ? 512 : 256) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // spare block (dispatched first, so it runs beside the row groups, not after them): the double-precision pow()
     // of Adam's bias corrections, off every row group's critical path
@@ -247,13 +256,13 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
         const float* b1 = W + tr.b1;
         const float* b2 = W + tr.b2;
         const float* bh = W + tr.bh;
-        sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        sg_layer_nt_u<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         __syncthreads();
         SG_PPO_STAMP(2);
-        sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        sg_layer_nt_u<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
         SG_PPO_STAMP(3);
-        sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
+        sg_layer_nt_u<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
         __syncthreads();
         SG_PPO_STAMP(4);
     }
@@ -316,7 +325,14 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
                     en += 0.5f + HALF_LOG_2PI + lsig;
                 }
             }
-            for (int o = 1; o < L; o <<= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); }
+            if (L <= 16) {   // L = 4, 8 or 16 consecutive lanes inside one DPP row: VALU butterflies, no LDS crossbar
+                lp = sg_dpp_add<0xB1>(lp); en = sg_dpp_add<0xB1>(en);
+                lp = sg_dpp_add<0x4E>(lp); en = sg_dpp_add<0x4E>(en);
+                if (L >= 8) { lp = sg_dpp_add<0x141>(lp); en = sg_dpp_add<0x141>(en); }
+                if (L >= 16) { lp = sg_dpp_add<0x140>(lp); en = sg_dpp_add<0x140>(en); }
+            } else {
+                for (int o = 1; o < L; o <<= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); }
+            }
             const float logp = lp, ent = en;
             const bool valid = VALID[r];
             float dlogp = 0.f, la = 0.f;
@@ -412,10 +428,10 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     }
     float* g = slab + tr.off;
     // head weight / bias gradients (needs h2 before it is overwritten)
-    sg_grad_tn<MT>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
+    sg_grad_tn<MT, (FUSED && MT >= 2 ? 8 : 0)>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
     sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
     if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
-    __syncthreads();
+    if (FUSED) SG_LDS_SYNC(); else __syncthreads();
     SG_PPO_STAMP(11);
     // dZ = (dY W) * (1 - h^2) in place over h; the bias gradient falls out of the epilogue registers
     auto dz_epilogue = [&](float* h, float* gb) {
@@ -435,6 +451,24 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
             if (lq == 0) gb[c] = sb;
         };
     };
+    if (FUSED) {
+        // per-tile tasks; dZ = (dY W) * (1 - h^2) in place over h, the bias gradient from column sums of the finished tile
+        auto dz_u = [&](float* h) { return [=](int r, int c, float v) { float* ph = h + r * ldH + c; const float hv = *ph; *ph = v * (1.f - hv * hv); }; };
+        sg_layer_nn_u<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_u(H2));
+        SG_LDS_SYNC();
+        SG_PPO_STAMP(12);
+        sg_grad_tn<MT, (MT >= 2 ? 8 : 0)>(H2, ldH, H1, ldH, Hp, Hp, g + tr.w2, ldH, false);
+        SG_PPO_STAMP(5);
+        sg_colsum(H2, ldH, R, Hp, g + tr.b2, false);
+        SG_LDS_SYNC();
+        SG_PPO_STAMP(13);
+        sg_layer_nn_u<MT>(H2, ldH, W + tr.w2, ldH, Hp, Hp, dz_u(H1));
+        SG_LDS_SYNC();
+        SG_PPO_STAMP(14);
+        sg_grad_tn<MT, (MT >= 2 ? 8 : 0)>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
+        sg_colsum(H1, ldH, R, Hp, g + tr.b1, false);
+        SG_LDS_SYNC();
+    } else {
     sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_epilogue(H2, g + tr.b2));
     __syncthreads();
     SG_PPO_STAMP(12);
@@ -446,6 +480,7 @@ __global__ __launch_bounds__(256) void k_ppo_bwd(PpoArgs a) {
     SG_PPO_STAMP(14);
     sg_grad_tn<MT>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
     __syncthreads();
+    }
     SG_PPO_STAMP(15);
     SG_PPO_WALL(7);
 }

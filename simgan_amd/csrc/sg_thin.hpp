@@ -109,16 +109,5 @@ __device__ __forceinline__ float sg4_colsum(float v) {
     const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
-// sum over the 16 lanes (one DPP row) that hold one row's 16 columns of this wave, result in all 16 lanes:
-// quad butterflies, then the half-row and row mirrors (every lane of a quad already holds the quad's sum)
-template <int CTRL>
-__device__ __forceinline__ float sg4_dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float sg4_rowsum16(float v) {
-    v = sg4_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = sg4_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = sg4_dpp_add<0x141>(v);   // row_half_mirror
-    v = sg4_dpp_add<0x140>(v);   // row_mirror
-    return v;
-}
+// sum over the 16 lanes (one DPP row) that hold one row's 16 columns of this wave, result in all 16 lanes (sg_gemm.hpp)
+__device__ __forceinline__ float sg4_rowsum16(float v) { return sg_rowsum16(v); }
