@@ -70,9 +70,15 @@ static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT) {
 #define SG_PPO_SHAPES(X) X(1, 3, 4) X(2, 3, 4) /* north-star: obs 47, h64 */ X(2, 1, 7) /* HopperCombined: obs 14, h100 */ \
                          X(2, 4, 7) /* LaikagoCombined: obs 64, h100 */ X(2, 7, 4) /* Laikago refinement: obs 111, h64 */
 
+// 8 waves once a workgroup has two row tiles to deal out (SG_PPO_WAVES=4: tuning knob, 4 waves always)
+static int ppo_block_threads(int MT) {
+    const char* we = getenv("SG_PPO_WAVES");
+    return (MT >= 2 && !(we && atoi(we) == 4)) ? 512 : 256;
+}
+
 static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
-    const dim3 block(256);
+    const dim3 block(ppo_block_threads(MT));
 #define SG_CASE(mt, o, h) \
     if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_SHAPES(SG_CASE)
@@ -83,10 +89,8 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
 }
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
-    dim3 block(256);
+    const dim3 block(ppo_block_threads(MT));
     if (fused) {   // Policy (independent actor / critic trunks): forward recomputed inside, no k_ppo_fwd launch
-        const char* we = getenv("SG_PPO_WAVES");   // tuning knob: 4 or 8 waves per workgroup
-        if (!(we && atoi(we) == 4)) block = dim3(MT >= 2 ? 512 : 256);   // 8 waves once a workgroup has two row tiles to deal out
         if (MT == 1 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true>), grid, block, lds, pa);

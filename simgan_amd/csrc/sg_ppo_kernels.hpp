@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_ppo_epoch_gather(EpochGatherArgs a) {
 
 // --------------------------------------------------------------------------------- forward
 template <int MT, int KO, int KH>
-__global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
+__global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
@@ -135,21 +135,21 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
     float* gH1 = a.H1[t] + (size_t)row0 * ldH;
     float* gH2 = a.H2[t] + (size_t)row0 * ldH;
     float* gOUT = a.OUT[t] + (size_t)row0 * ldP;
-    sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) {
+    sg_layer_nt_u<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b1[c]);
         H1[r * ldH + c] = h;
         gH1[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(3);
-    sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) {
+    sg_layer_nt_u<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b2[c]);
         H2[r * ldH + c] = h;
         gH2[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(4);
-    sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
+    sg_layer_nt_u<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
     __syncthreads();
     SG_PPO_STAMP(5);
 }
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void k_ppo_fwd(PpoArgs a) {
 // FUSED (Policy: the actor and critic trunks do not depend on each other's outputs): the workgroup stages the
 // whole trunk, recomputes the forward on its own rows in LDS and goes straight on to the loss -- no k_ppo_fwd
 // launch, no activation stacks written, flushed and read back (5 MB per step at the north-star shape).
-// The fused form runs with 8 waves (512 threads) when the launch code asks for it: the layer GEMMs are then dealt out per
-// 16x16 output tile (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per
-// SIMD hide each other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights
-// staged once and one slab per 32 rows.
+// Launched with 8 waves (512 threads) for 32-row groups and up: the layer GEMMs are dealt out per 16x16 output tile
+// (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per SIMD hide each
+// other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights staged once and
+// one slab per 32 rows.
 template <int MT, int KO, int KH, bool FUSED = false>
-__global__ __launch_bounds__(FUSED ? 512 : 256) void k_ppo_bwd(PpoArgs a) {
+__global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // spare block (dispatched first, so it runs beside the row groups, not after them): the double-precision pow()
     // of Adam's bias corrections, off every row group's critical path
@@ -428,30 +428,12 @@ __global__ __launch_bounds__(FUSED ? 512 : 256) void k_ppo_bwd(PpoArgs a) {
     }
     float* g = slab + tr.off;
     // head weight / bias gradients (needs h2 before it is overwritten)
-    sg_grad_tn<MT, (FUSED && MT >= 2 ? 8 : 0)>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
+    sg_grad_tn<MT, (MT >= 2 ? 8 : 0)>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
     sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
     if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
-    if (FUSED) SG_LDS_SYNC(); else __syncthreads();
+    SG_LDS_SYNC();
     SG_PPO_STAMP(11);
-    // dZ = (dY W) * (1 - h^2) in place over h; the bias gradient falls out of the epilogue registers
-    auto dz_epilogue = [&](float* h, float* gb) {
-        return [=](int tn, f32x4 (&acc)[MT][1]) {
-            const int c = tn * 16 + (tid & 15), lq = (tid & 63) >> 4;
-            float z[MT][4];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* ph = h + (i * 16 + 4 * lq + r) * ldH + c;
-                    const float hv = *ph;
-                    z[i][r] = acc[i][0][r] * (1.f - hv * hv);
-                    *ph = z[i][r];
-                }
-            const float sb = sg_tile_colsum<MT>(z);
-            if (lq == 0) gb[c] = sb;
-        };
-    };
-    if (FUSED) {
+    {
         // per-tile tasks; dZ = (dY W) * (1 - h^2) in place over h, the bias gradient from column sums of the finished tile
         auto dz_u = [&](float* h) { return [=](int r, int c, float v) { float* ph = h + r * ldH + c; const float hv = *ph; *ph = v * (1.f - hv * hv); }; };
         sg_layer_nn_u<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_u(H2));
@@ -468,18 +450,6 @@ __global__ __launch_bounds__(FUSED ? 512 : 256) void k_ppo_bwd(PpoArgs a) {
         sg_grad_tn<MT, (MT >= 2 ? 8 : 0)>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
         sg_colsum(H1, ldH, R, Hp, g + tr.b1, false);
         SG_LDS_SYNC();
-    } else {
-    sg_layer_nn_t<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_epilogue(H2, g + tr.b2));
-    __syncthreads();
-    SG_PPO_STAMP(12);
-    sg_grad_tn<MT>(H2, ldH, H1, ldH, Hp, Hp, g + tr.w2, ldH, false);
-    __syncthreads();
-    SG_PPO_STAMP(13);
-    sg_layer_nn_t<MT>(H2, ldH, W + tr.w2, ldH, Hp, Hp, dz_epilogue(H1, g + tr.b1));
-    __syncthreads();
-    SG_PPO_STAMP(14);
-    sg_grad_tn<MT>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
-    __syncthreads();
     }
     SG_PPO_STAMP(15);
     SG_PPO_WALL(7);
