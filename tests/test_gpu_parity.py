@@ -744,3 +744,23 @@ def test_injected_draws_are_validated(sg):
     a_ = D.update_gail_dyn(loader, ro)
     b_ = D2.update_gail_dyn(loader, ro, *D.last_draws())      # replaying exported draws reproduces the epoch bit for bit
     assert a_ == b_ and np.array_equal(D.get_flat_params(), D2.get_flat_params())
+
+
+KNOBS = [{"SG_PPO_FUSED": "0"}, {"SG_PPO_ROWS": "16"}, {"SG_PPO_ROWS": "32"}, {"SG_PPO_WAVES": "4"}, {"SG_DISC_CHAIN": "wide"},
+         {"SG_PPO_GRAPH": "0", "SG_DISC_GRAPH": "0"}, {"SG_WGRAD_XCD": "0"}]
+
+
+@pytest.mark.parametrize("knob", KNOBS, ids=[",".join(f"{k}={v}" for k, v in kn.items()) for kn in KNOBS])
+def test_every_launch_variant_keeps_parity(knob):
+    """The library's environment knobs select other kernels / launch geometries for the same math (unfused PPO forward,
+    16- or 32-row PPO groups, 4-wave PPO workgroups, the 16-row discriminator chain kernel, direct launches instead of graph
+    replay, the linear weight-gradient tile order): the reference trajectories must hold under each of them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **knob)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-p", "no:cacheprovider", "-k", "ppo_update_golden or disc_update_golden or full_iteration_golden or refine_iteration_golden"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
