@@ -623,9 +623,9 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
 #pragma unroll
             for (int q = 0; q < KF; ++q) { const float v = GX[s * ldAF + 16 * q + cl]; ss += v * v; }
             ss = sg4_rowsum16(ss);
-            const float nn = sqrtf(ss);
-            const bool valid = bi0 + s < a.B;
-            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) / nn : 0.f;
+            const float nn = __builtin_amdgcn_sqrtf(ss);                      // v_sqrt_f32 / v_rcp_f32 (1 ulp): the correctly rounded
+            const bool valid = bi0 + s < a.B;                                 // sequences are ~60 VALU instructions on this phase's path
+            const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) * __builtin_amdgcn_rcpf(nn) : 0.f;
             if (actF) R1t[SG_STK(Kt, rowA + s, col)] = gown * cr;                // gb
             if (wave == 0) {
                 const float rl = sg4_colsum(valid ? (nn - 1.f) * (nn - 1.f) : 0.f);
