@@ -483,7 +483,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             wa.next = pg;
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
             else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
-            SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa);
+            SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa.ops, wa.params, wa.m,
+                      wa.v, wa.st, wa.G, dd.Hp, dd.Fp, (wa.xcd_map ? 1 : 0) | (wa.grad_out ? 2 : 0) | (wa.dbg ? 4 : 0), wa);
             if (sharded) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
                 hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,

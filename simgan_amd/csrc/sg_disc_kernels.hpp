@@ -729,16 +729,29 @@ __device__ __forceinline__ void sg_adam_apply(float* p, float* m, float* v, floa
 
 #define SG_WGRAD_THREADS 512
 
-__global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
+// The first 16 dwords of the argument list are what a weight-tile block needs to form its operand addresses (and its
+// parameter / moment addresses): the code object asks the command processor to preload them into SGPRs
+// (-amdgpu-kernarg-preload-count), so the operand loads -- the block's critical path -- do not first wait for a kernarg
+// fetch from memory after a fresh launch.  Everything else rides in the struct behind them and is read when it is needed.
+__global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_ops, float* c_params, float* c_m, float* c_v,
+                                                                const SgOptState* c_st, int c_G, int c_Hp, int c_Fp,
+                                                                int c_flags /* 1: xcd_map, 2: grad_out set, 4: dbg set */,
+                                                                WgradArgs a) {
     __shared__ float red[8][256];
-    const SgDiscDesc& d = a.d;
+    SgDiscDesc d;   // same arithmetic as sg_make_disc_desc, from the preloaded extents
+    d.F = 0; d.Hd = 0;
+    d.Hp = c_Hp; d.Fp = c_Fp; d.ldF = c_Fp + 4; d.ldH = c_Hp + 4;
+    d.w1 = 0; d.b1 = d.Hp * d.ldF; d.w2 = d.b1 + d.Hp; d.b2 = d.w2 + d.Hp * d.ldH;
+    d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
+    a.ops = c_ops; a.params = c_params; a.m = c_m; a.v = c_v; a.st = c_st; a.G = c_G; a.xcd_map = c_flags & 1;
+    const bool has_grad_out = c_flags & 2, has_dbg = c_flags & 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
     const int nw = blockDim.x >> 6;
     const int th = d.Hp >> 4, tf = d.Fp >> 4;
     const int T2 = th * th, T1 = th * tf;
     const int Kt = 64 * a.G;
     // test hook: wall clock (100 MHz) at block start / after the operand loads / after the LDS reduce / end
-    long long* stamp = (a.dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
+    long long* stamp = (has_dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
     if (stamp) stamp[0] = wall_clock64();
     int b;
     if (a.xcd_map) {
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         float p0 = 0.f, m0 = 0.f, v0 = 0.f;
         float4 sc = float4{0.f, 0.f, 1.f, 1.f};   // both slots of the Adam scalars; the step's parity picks one at the end
         int t0 = 0;
-        if (tid < 256 && !a.grad_out) {
+        if (tid < 256 && !has_grad_out) {
             p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx];
             sc = *reinterpret_cast<const float4*>(a.st->step_size2);
             t0 = a.st->t0;
@@ -864,7 +877,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(WgradArgs a) {
         const bool odd = (a.st->t0 + a.k1) & 1;
         const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
         // the element's parameter and moments are requested with the partials: one memory round trip per block
-        const bool is_param = wave == 0 && i < 3 * Hp + 1 && !a.grad_out;
+        const bool is_param = wave == 0 && i < 3 * Hp + 1 && !has_grad_out;
         const int pidx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
         float pv = 0.f, pm = 0.f, pvv = 0.f;
         if (is_param) { pv = a.params[pidx]; pm = a.m[pidx]; pvv = a.v[pidx]; }

@@ -339,8 +339,8 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
                     hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
-                          a->d_grad, a->d_part, ctx->use_comm ? nblk : nblk_r, d.total, st, a->cfg.eps, a->cfg.max_grad_norm,
-                          pa.inv_B, a->d_loss_acc, e * M + k + 1);
+                          a->d_grad, a->d_part, ctx->use_comm ? nblk : nblk_r, d.total, st, e * M + k + 1, a->cfg.eps, a->cfg.max_grad_norm,
+                          pa.inv_B, a->d_loss_acc);
             }
         }
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, st, E * M);

@@ -500,10 +500,11 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* grad, int total, flo
 }
 
 // clip_grad_norm_ + Adam (a2c/algo/ppo.py:143-145; torch.optim.Adam single-tensor math).
+// (argument order: everything the first instructions need sits in the 16 dwords the command processor preloads)
 __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float* v, const float* grad,
                                                   const float* part, int n_part, int total,
-                                                  const SgOptState* st, float eps, float max_norm,
-                                                  float inv_mb, double* loss_acc, int k1) {
+                                                  const SgOptState* st, int k1, float eps, float max_norm,
+                                                  float inv_mb, double* loss_acc) {
     __shared__ float s_coef;
     // Adam step t = st->t0 + k1; its bias-correction scalars were prepared in slot t & 1 by this step's k_ppo_bwd
     const int t = st->t0 + k1;
