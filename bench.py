@@ -58,8 +58,10 @@ class Loader:
         self.expert, self.batch_size = expert, batch_size
 
 
-def algorithmic_work(w, world):
-    """Per-update algorithmic FLOPs and HBM bytes for ONE rank (SURVEY.md 8(d) formulas)."""
+def algorithmic_work(w, world, disc_sharded=False):
+    """Per-update algorithmic FLOPs and HBM bytes for ONE rank (SURVEY.md 8(d) formulas).  world > 1: the PPO rows are
+    always sharded; the discriminator's are only in sharded mode -- in the default replicated mode every rank runs the
+    full-batch steps."""
     T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
     TN = T * N
     n_d = min(w["Ne"] // B, TN * world // B) if w["E_d"] else 0
@@ -73,13 +75,14 @@ def algorithmic_work(w, world):
         n_tr = 3
     ppo_flops_row = 2 * (3 * fwd - n_tr * O * H)
     mb = TN // w["M"]
-    d_step_flops = (B // world) * d_flops_triple
-    d_wgrad_flops = (B // world) * 2 * 4 * (F * Hd + Hd * Hd)   # dW1, dW2 over expert + policy + 2 mixup terms
+    B_rank = B // world if disc_sharded else B
+    d_step_flops = B_rank * d_flops_triple
+    d_wgrad_flops = B_rank * 2 * 4 * (F * Hd + Hd * Hd)   # dW1, dW2 over expert + policy + 2 mixup terms
     d_chain_flops = d_step_flops - d_wgrad_flops                 # forward + activation backward + double backward
     ppo_step_flops = mb * ppo_flops_row
     relabel_flops = TN * 2 * Wd if w["E_d"] else 0
     flops = w["E_d"] * n_d * d_step_flops + w["E_p"] * w["M"] * ppo_step_flops + relabel_flops
-    bytes_ = (w["E_d"] * n_d * 2 * (B // world) * F * 4 + (TN * (F + 2) * 4 if w["E_d"] else 0) + TN * 20 + TN * 12 +
+    bytes_ = (w["E_d"] * n_d * 2 * B_rank * F * 4 + (TN * (F + 2) * 4 if w["E_d"] else 0) + TN * 20 + TN * 12 +
               w["E_p"] * w["M"] * mb * (O + A + 4) * 4)
     return dict(n_d=n_d, d_step_flops=d_step_flops, d_chain_flops=d_chain_flops, d_wgrad_flops=d_wgrad_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
                 d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"])
@@ -259,7 +262,7 @@ def main():
         ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam"])}
 
     if rank == 0:
-        work = algorithmic_work(w, world)
+        work = algorithmic_work(w, world, ctx.disc_sharded)
         env_steps = w["T"] * w["N"] * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = env_steps * args.steps / elapsed
