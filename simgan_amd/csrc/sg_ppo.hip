@@ -319,6 +319,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     // and the PPO coefficients: the learning rate and Adam's step count live on the device.  The sequence is
     // captured into a hipGraph once and replayed per update, so the host issues one call instead of ~650.
     auto enqueue_steps = [&]() -> int {
+        hipLaunchKernelGGL(k_opt_prepare_first, dim3(1), dim3(1), 0, ctx->stream, st);
         for (int e = 0; e < E; ++e) {
             ga.perm = a->d_perms + (size_t)e * TN;
             hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
@@ -331,7 +332,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
                 }
                 pa.wbuf_floats = fused ? wb_f : wb_b;
                 pa.k1 = e * M + k + 1;
-                launch_ppo_bwd(ctx, MT, d, dim3(G + 1, d.n_trunks), lds_b, pa, fused);
+                launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused);
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
                           d.total, a->d_grad, a->d_part);
                 if (ctx->use_comm) {

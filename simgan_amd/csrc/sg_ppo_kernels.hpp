@@ -43,8 +43,8 @@ struct PpoArgs {
     int ldP;              // stride of the OUT stacks (max over trunks)
     int wbuf_floats;
     long long* dbg;       // optional phase timestamps [block][16] (test hook), NULL in production
-    SgOptState* st;       // k_ppo_bwd: one spare lane prepares this step's Adam scalars (step st->t0 + k1)
-    int k1, G;            // 1-based step index within the update; row groups (k_ppo_bwd: blockIdx.x == 0 is the spare block)
+    SgOptState* st;       // optimizer scalars (read by k_ppo_adam; prepared one step ahead by the previous k_ppo_adam)
+    int k1, G;            // 1-based step index within the update; row groups
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): in the backward phases that is
@@ -165,13 +165,10 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
 template <int MT, int KO, int KH, bool FUSED = false>
 __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // spare block (dispatched first, so it runs beside the row groups, not after them): the double-precision pow()
-    // of Adam's bias corrections, off every row group's critical path
-    if (blockIdx.x == 0) {
-        if (blockIdx.y == 0 && threadIdx.x == 0) sg_opt_prepare(a.st, a.st->t0 + a.k1);
-        return;
-    }
-    const int bx = blockIdx.x - 1;   // row group
+    // (No spare workgroup for Adam's bias corrections any more: with G x trunks = 256 row-group blocks, two extra blocks
+    // made 258 for 256 CUs, and whenever the dispatcher doubled two row groups up on one CU before the spare blocks had
+    // exited, those pairs finished 4 us after everyone else.  k_ppo_adam prepares the NEXT step's scalars instead.)
+    const int bx = blockIdx.x;   // row group
     constexpr int R = 16 * MT;
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
@@ -318,10 +315,14 @@ __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
                     if (mlp) { pmv[j] = o0 + k; plv[j] = o1 + k; mean = *pmv[j]; ls = W[tra.ex + k]; }
                     else if (k < d.nc) { pmv[j] = o0 + k; plv[j] = o0 + d.nc + k; mean = *pmv[j]; ls = *plv[j]; }
                     else { pmv[j] = o1 + (k - d.nc); plv[j] = o1 + (d.na + k - d.nc); mean = *pmv[j]; ls = *plv[j]; }
-                    sig[j] = expf(ls);
+                    // hardware exp2 / rcp (1 ulp) and log(exp(ls)) taken as ls: relative deviations of 1e-7 against the
+                    // reference's libm chain, four orders below the tolerance of the per-step parity tests, and 0.9k
+                    // cycles less on the one phase where every wave of the block waits on transcendental latency
+                    sig[j] = __expf(ls);
                     dif[j] = ACT[r * A + k] - mean;
-                    const float lsig = logf(sig[j]);
-                    lp += -(dif[j] * dif[j]) / (2.f * sig[j] * sig[j]) - lsig - HALF_LOG_2PI;
+                    const float lsig = ls;
+                    sig[j] = __builtin_amdgcn_rcpf(sig[j] * sig[j]);   // 1 / var from here on
+                    lp += -0.5f * (dif[j] * dif[j]) * sig[j] - lsig - HALF_LOG_2PI;
                     en += 0.5f + HALF_LOG_2PI + lsig;
                 }
             }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
             float dlogp = 0.f, la = 0.f;
             if (valid) {
                 const float adv = SC[1 * R + r];
-                const float ratio = expf(logp - SC[0 * R + r]);
+                const float ratio = __expf(logp - SC[0 * R + r]);
                 const float surr1 = ratio * adv;
                 const float surr2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * adv;
                 const float w1 = surr1 < surr2 ? 1.f : (surr1 > surr2 ? 0.f : 0.5f);  // torch.min tie -> 1/2, 1/2
@@ -351,9 +352,9 @@ __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int k = sub + j * L;
                 if (k < A) {
-                    const float var = sig[j] * sig[j];
-                    *pmv[j] = dlogp * dif[j] / var;
-                    *plv[j] = dlogp * (dif[j] * dif[j] / var - 1.f) - dent;
+                    const float rvar = sig[j];
+                    *pmv[j] = dlogp * dif[j] * rvar;
+                    *plv[j] = dlogp * (dif[j] * dif[j] * rvar - 1.f) - dent;
                 } else if (mlp && k < tra.Pp) {
                     o1[k] = 0.f;   // o1 doubles as the per-row d/d logstd tile: clear its padding columns
                 }
@@ -488,6 +489,9 @@ __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_sl
     }
 }
 
+// Adam scalars of the update's first step (every later step's are prepared by the preceding k_ppo_adam)
+__global__ void k_opt_prepare_first(SgOptState* st) { sg_opt_prepare(st, st->t0 + 1); }
+
 // sum of squares only (data-parallel mode: recomputed after the all-reduce)
 __global__ __launch_bounds__(256) void k_sumsq(const float* grad, int total, float* part) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,6 +540,8 @@ __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float
     }
     if (blockIdx.x == 0 && threadIdx.x < 3)  // value_loss.item() etc. are float32, summed in Python doubles
         loss_acc[threadIdx.x] += (double)(grad[total + threadIdx.x] * inv_mb);
+    // the next step's bias corrections (double pow) into the other slot: nobody reads that slot before the next k_ppo_adam
+    if (blockIdx.x == 0 && threadIdx.x == 64) sg_opt_prepare(const_cast<SgOptState*>(st), t + 1);
 }
 
 // adv = returns[:-1] - value_preds[:-1]; sums for mean / unbiased std (a2c/algo/ppo.py:66-68)
