@@ -1,0 +1,99 @@
+"""Randomised-shape parity sweep: the HIP path against the CPU oracle on shapes nobody hand-picked.
+
+Every case draws its dimensions from its seed -- observation / action / hidden widths that are not multiples of the
+16-column tiles, rollouts whose T*N does not divide into the minibatches, discriminator batches that are not multiples of
+the 4-row / 16-row blocks, expert sets with a ragged tail -- and runs two updates (the second continues the Adam state and,
+where the shape allows it, replays the captured graph).  Same tolerance as tests/test_gpu_parity.py (1e-4 relative fp32).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+from test_gpu_parity import Box, Loader
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import simgan_amd
+    return simgan_amd
+
+
+def _npv(x):
+    return x.numpy() if hasattr(x, "numpy") else np.asarray(x)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ppo_random_shapes_vs_oracle(sg, seed):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7000 + seed)
+    kind = "mlp" if seed % 2 == 0 else "split"
+    if kind == "mlp":
+        O, A, H, f = int(rng.integers(1, 120)), int(rng.integers(1, 20)), int(rng.choice([8, 24, 64, 100])), 1
+    else:
+        f = int(rng.integers(1, 5))
+        O, A, H = int(rng.integers(2, 70)), 7 * f, int(rng.choice([16, 64, 100]))
+    T, N = int(rng.integers(2, 12)), int(rng.integers(1, 40))
+    M = int(rng.integers(1, min(6, T * N) + 1))
+    E = int(rng.integers(1, 4))
+    clip, vcoef, ecoef = float(rng.choice([0.1, 0.2])), 0.5, float(rng.choice([0.0, 0.01]))
+    bk = {"recurrent": False, "hidden_size": H} if kind == "mlp" else {"hidden_size": H, "num_feet": f}
+    pol = (sg.Policy if kind == "mlp" else sg.SplitPolicy)((O,), Box((A,)), base_kwargs=bk, seed=seed)
+    ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, 1)
+    obs = rng.standard_normal((T + 1, N, O)).astype(np.float32)
+    ro.obs.copy_(ro.obs.new_tensor(obs))
+    v, a, lp, _ = pol.act(obs[:-1].reshape(-1, O), None, None, noise=rng.standard_normal((T * N, A)).astype(np.float32))
+    act, logp = _npv(a).reshape(T, N, A), _npv(lp).reshape(T, N, 1)
+    vp = np.concatenate([_npv(v).reshape(T, N, 1), np.zeros((1, N, 1), np.float32)])
+    ret = (vp + rng.standard_normal(vp.shape) * 0.5).astype(np.float32)
+    ro.actions.copy_(ro.actions.new_tensor(act)); ro.action_log_probs.copy_(ro.action_log_probs.new_tensor(logp))
+    ro.value_preds.copy_(ro.value_preds.new_tensor(vp)); ro.returns.copy_(ro.returns.new_tensor(ret))
+    p0 = (pol.get_flat_params() + 0.02 * rng.standard_normal(pol.num_params)).astype(np.float32)
+    pol.set_flat_params(p0)
+    agent = sg.algo.PPO(pol, clip, E, M, vcoef, ecoef, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    cfg = orc.ppo_cfg(clip, E, M, vcoef, ecoef, 3e-4, 1e-5, 0.5, True)
+    what = f"{kind} O={O} A={A} H={H} f={f} T={T} N={N} M={M} E={E}"
+    for u in range(2):
+        perms = np.stack([rng.permutation(T * N) for _ in range(E)]).astype(np.int64)
+        losses = agent.update(ro, perms=perms)
+        olosses = orc.ppo_update(d, par, adam, cfg, obs, act, vp[..., 0], ret[..., 0], logp[..., 0], perms)
+        assert_close(losses, olosses, what=f"PPO losses, update {u}, {what}")
+        assert_close(pol.get_flat_params(), par, what=f"policy params, update {u}, {what}")
+
+
+@pytest.mark.parametrize("chain", ["thin", "wide"])
+@pytest.mark.parametrize("seed", range(8))
+def test_disc_random_shapes_vs_oracle(sg, seed, chain, monkeypatch):
+    from oracle import oracle as orc
+    monkeypatch.setenv("SG_DISC_CHAIN", chain)
+    rng = np.random.default_rng(9000 + seed)
+    # the 4-row kernel exists for the shipped (F, Hd) tile counts; other widths take the 16-row kernel whatever `chain` says
+    F, Hd = [(86, 100), (25, 100), (int(rng.integers(1, 17)), int(rng.integers(1, 17))),
+             (int(rng.integers(17, 130)), int(rng.integers(17, 130)))][seed % 4]
+    B = int(rng.integers(1, 140))
+    T, N = int(rng.integers(2, 10)), int(rng.integers(1, 50))
+    Ne = int(rng.integers(B, 4 * B + 20))
+    if T * N < B:
+        N = (B + T - 1) // T
+    D = sg.algo.gail.Discriminator(F, Hd, None, seed=seed)
+    p0 = D.get_flat_params()
+    ro = sg.RolloutStorage(T, N, (3,), Box((2,)), 1, F)
+    feat = rng.standard_normal((T + 1, N, F)).astype(np.float32)
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(feat))
+    expert = (rng.standard_normal((Ne, F)) * 0.7 + 0.2).astype(np.float32)
+    n_d = min(Ne // B, (T * N) // B)
+    eperm = rng.permutation(Ne).astype(np.int64)
+    pperm = rng.permutation(T * N).astype(np.int64)
+    alpha = rng.random(n_d * B).astype(np.float32)
+    par, adam = p0.copy(), orc.AdamState(p0.size)
+    what = f"F={F} Hd={Hd} B={B} Ne={Ne} T={T} N={N}"
+    for u in range(2):
+        losses = D.update_gail_dyn(Loader(expert, B), ro, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+        assert D.last_n_steps == n_d
+        olosses, on = orc.disc_update(F, Hd, par, adam, expert, feat, B, eperm, pperm, alpha)
+        assert on == n_d
+        assert_close(losses, olosses, what=f"D losses, epoch {u}, {what}")
+        assert_close(D.get_flat_params(), par, what=f"D params, epoch {u}, {what}")
