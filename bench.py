@@ -203,6 +203,16 @@ def main():
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
     args = ap.parse_args()
 
+    # Exactly ONE line on stdout: RCCL (and anything else underneath) writes banners to the C-level stdout, which would land
+    # before or after the JSON line depending on buffering.  Everything written to fd 1 from here on goes to stderr; the
+    # result line is written to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     from simgan_amd.dist import ProcessGroup
     pg = ProcessGroup()
     rank, world = pg.rank, pg.world
@@ -215,6 +225,8 @@ def main():
     ctx = _lib.Context.default()   # device = LOCAL_RANK
     lib = ctx.lib
     pg.init_device_comm(ctx, _lib.comm_unique_id)
+    if world == 1 and os.environ.get("SG_COMM_ALWAYS") == "1":   # one-rank communicator: the collectives run as identities
+        ctx.comm_init(_lib.comm_unique_id(), 0, 1)
 
     w = WORKLOADS[args.workload]
     pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, seed=0)
@@ -238,21 +250,8 @@ def main():
         return pg.max(mine), pg.gather(mine), last_
 
     elapsed, per_rank, last = timed(args.steps, args.warmup)
-    # N > 1: the discriminator has two data-parallel modes (DESIGN.md section 6).  `value` is the default (replicated:
-    # every rank runs the full-batch steps on the union of the ranks' rows, no per-step collective); the sharded mode
-    # (batch/world rows per rank, one gradient all-reduce per step) is timed as well and reported beside it.
-    alt = None
-    if world > 1 and w["E_d"] and not args.no_other_disc_mode:
-        k2 = max(2, args.steps // 2)
-        try:
-            ctx.set_disc_dp(not ctx.disc_sharded)
-            e2, pr2, _ = timed(k2, 2)
-            alt = dict(mode="sharded" if ctx.disc_sharded else "replicated", steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
-                       value=round(w["T"] * w["N"] * world * k2 / e2, 1), per_rank_ms_per_step=[round(1e3 * x / k2, 3) for x in pr2])
-        except Exception as exc:   # the headline measurement above is already complete: report, do not lose the line
-            alt = dict(mode="sharded" if ctx.disc_sharded else "replicated", error=str(exc)[:300])
-        ctx.set_disc_dp(not ctx.disc_sharded)
-
+    # self-test of the N > 1 reporting path on one GPU (with SG_COMM_ALWAYS=1 the collectives stay in the launch sequence)
+    force_alt = world == 1 and os.environ.get("SG_BENCH_FORCE_ALT") == "1" and ctx.comm_info()[1] == 1 and os.environ.get("SG_COMM_ALWAYS") == "1"
     # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
     ctx.profile_reset()
     ctx.profile(True)
@@ -308,16 +307,47 @@ def main():
             "device": name, "num_cu": num_cu,
             "per_rank_ms_per_step": [round(1e3 * x / args.steps, 3) for x in per_rank],
         }
-        if world > 1:
+        if world > 1 or force_alt:
             out["comm"] = {"backend": "RCCL (dlopen) on the library stream, captured into the update's hipGraphs",
                            "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
                            "disc_mode": "sharded" if ctx.disc_sharded else "replicated"}
-            if alt:
-                out["comm"]["disc_other_mode"] = alt
+    else:
+        out = None
+    # N > 1: the discriminator has two data-parallel modes (DESIGN.md section 6).  `value` is the default (replicated:
+    # every rank runs the full-batch steps on the union of the ranks' rows, no per-step collective); the sharded mode
+    # (batch/world rows per rank, one gradient all-reduce per step) is timed as well and reported beside it.  The headline
+    # line is complete at this point: a watchdog on every rank prints it and ends the run if the extra measurement stalls.
+    if (world > 1 or force_alt) and w["E_d"] and not args.no_other_disc_mode:
+        import threading
+        k2 = max(2, args.steps // 2)
+        other = "replicated" if ctx.disc_sharded else "sharded"
+        budget = max(90.0, 10.0 * elapsed * (k2 + 2) / args.steps)
+
+        def give_up():
+            if rank == 0:
+                out["comm"]["disc_other_mode"] = dict(mode=other, error=f"no result within {budget:.0f} s; measurement abandoned")
+                emit(out)
+            os._exit(0)
+
+        dog = threading.Timer(budget, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            ctx.set_disc_dp(not ctx.disc_sharded)
+            e2, pr2, _ = timed(k2, 2)
+            alt = dict(mode=other, steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
+                       value=round(w["T"] * w["N"] * world * k2 / e2, 1), per_rank_ms_per_step=[round(1e3 * x / k2, 3) for x in pr2])
+        except Exception as exc:   # the headline measurement above is already complete: report, do not lose the line
+            alt = dict(mode=other, error=str(exc)[:300])
+        dog.cancel()
+        ctx.set_disc_dp(not ctx.disc_sharded)
+        if rank == 0:
+            out["comm"]["disc_other_mode"] = alt
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, expert, args.cpu_seconds)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        print(json.dumps(out))
+        emit(out)
     pg.shutdown()
 
 
