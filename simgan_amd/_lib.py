@@ -169,7 +169,14 @@ class Context:
     def default():
         dev = int(os.environ.get("LOCAL_RANK", "0"))
         if dev not in _CTX:
-            _CTX[dev] = Context(dev)
+            try:
+                _CTX[dev] = Context(dev)
+            except SimganHipError as exc:
+                # a launcher that narrows the visible devices per rank (HIP_/ROCR_VISIBLE_DEVICES) leaves each rank one
+                # device, numbered 0; anything else about the device is a real error
+                if dev == 0 or "out of range (1 visible)" not in str(exc):
+                    raise
+                _CTX[dev] = Context(0)
         return _CTX[dev]
 
     def synchronize(self):
