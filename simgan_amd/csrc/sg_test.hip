@@ -368,6 +368,82 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int wor
 
 // Test hook: how the last update of each object was issued -- 0 direct launches, 1 replayed graph, 2 a capture was
 // refused once and the object fell back to direct launches (tests/test_gpu_comm.py).
+// ---------------------------------------------------------------------------------------------------------------
+// Fetch probe (tools/fetch_probe.py): how fast ONE CU takes in a weight image the way k_disc_chain4 does -- every wave
+// of a block requests NL 16-byte-per-lane loads (1 KiB per instruction) of a buffer another kernel has just written,
+// all blocks the same addresses (mode bit 0 clear) or each block its own copy (bit 0 set); bit 1: 4-byte loads of the
+// same bytes (4x the instructions); bit 2: only the lower 32 lanes of every wave load.  A second pass inside the same
+// launch re-reads the data (now in this XCD's L2); bit 3: the writer uses nontemporal stores.
+// out[block] = {cycles first pass, cycles second pass, cycles until the first load of the first pass has returned}.
+__global__ void k_fetch_fill(float* p, size_t n, int nt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (nt) __builtin_nontemporal_store(1.0f, p + i);
+        else p[i] = 1.0f;
+    }
+}
+template <int NL>
+__global__ __launch_bounds__(512) void k_fetch_probe(const float* src, int mode, size_t block_stride_f, long long* out, float* sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* base = src + ((mode & 1) ? (size_t)blockIdx.x * block_stride_f : 0) + (size_t)wave * NL * 256;
+    float acc = 0.f;
+    long long cyc[2], first = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        const long long t0 = clock64();
+        if (!(mode & 4) || lane < 32) {
+            if (mode & 2) {
+                float v[NL][4];
+#pragma unroll
+                for (int t = 0; t < NL; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[t][j] = __builtin_nontemporal_load(base + t * 256 + j * 64 + lane) * 0.f + base[t * 256 + j * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < NL; ++t) acc += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+            } else {
+                float4 v[NL];
+                // one wave-uniform descriptor, immediate offsets: the loads issue back to back (sg_stage_issue's pattern)
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+                const int boff = (int)((base - src) * 4) + lane * 16;
+#pragma unroll
+                for (int t = 0; t < NL; ++t) v[t] = sg_buffer_load4(rsrc, boff + t * 1024);
+                acc += v[0].x;   // the first load's round trip
+                __builtin_amdgcn_sched_barrier(0);
+                if (pass == 0 && threadIdx.x == 0) first = clock64() - t0;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NL; ++t) acc += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cyc[pass] = clock64() - t0;
+    }
+    if (threadIdx.x == 0) { out[3 * blockIdx.x] = cyc[0]; out[3 * blockIdx.x + 1] = cyc[1]; out[3 * blockIdx.x + 2] = first; }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+extern "C" int sg_test_fetch_probe(sg_ctx* ctx, int n_blocks, int waves, int mode, long long* out) {
+    SG_REQUIRE(ctx && out && n_blocks > 0 && n_blocks <= 1024 && waves >= 1 && waves <= 8, "sg_test_fetch_probe: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    constexpr int NL = 27;
+    const size_t per_block_f = (size_t)8 * NL * 256;
+    const size_t n = per_block_f * ((mode & 1) ? (size_t)n_blocks : 1);
+    float *d_src, *d_sink;
+    long long* d_out;
+    SG_CHECK(hipMalloc((void**)&d_src, sizeof(float) * n));
+    SG_CHECK(hipMalloc((void**)&d_sink, 64));
+    SG_CHECK(hipMalloc((void**)&d_out, sizeof(long long) * 3 * n_blocks));
+    for (int rep = 0; rep < 6; ++rep) {   // last repetition is the one reported (warm code, warm TLB); the data is rewritten before each
+        hipLaunchKernelGGL(k_fetch_fill, dim3(256), dim3(256), 0, ctx->stream, d_src, n, (mode >> 3) & 1);
+        hipLaunchKernelGGL(k_fetch_probe<NL>, dim3(n_blocks), dim3(64 * waves), 0, ctx->stream, d_src, mode, per_block_f, d_out, d_sink);
+    }
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_CHECK(hipMemcpy(out, d_out, sizeof(long long) * 3 * n_blocks, hipMemcpyDeviceToHost));
+    (void)hipFree(d_src); (void)hipFree(d_sink); (void)hipFree(d_out);
+    return 0;
+}
+
 extern "C" int sg_test_graph_state(sg_ppo* a, sg_disc* d, int out[2]) {
     SG_REQUIRE(out, "sg_test_graph_state: NULL argument");
     out[0] = a ? (a->graph_refused ? 2 : (a->steps_graph ? 1 : 0)) : -1;
