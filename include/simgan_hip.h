@@ -50,7 +50,14 @@ int sg_ctx_device_info(sg_ctx *ctx, char *name, int name_len, int *num_cu, int64
  * reference (single process, a2c/main_gail_dyn_ppo.py:64); added per BASELINE.json north_star.
  * id is the 128-byte ncclUniqueId produced on rank 0 and broadcast by the host launcher. */
 int sg_comm_unique_id(uint8_t id[128]);
+/* An id for the LOOPBACK transport instead: `world` contexts of ONE host (threads or processes, any devices -- also all
+ * on the same device) exchange through a shared-memory segment named by the id; sg_ctx_comm_init recognises the id's
+ * tag.  Every world > 1 code path of the library then runs on a one-GPU box (tests, bench.py --loopback); it
+ * synchronises the stream per collective and is not a performance path. */
+int sg_comm_loopback_id(uint8_t id[128]);
 int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
+/* *kind = 0 no communicator, 1 RCCL, 2 loopback. */
+int sg_ctx_comm_kind(sg_ctx *ctx, int *kind);
 /* rank / world as the communicator itself reports them (ncclCommUserRank / ncclCommCount) once it exists. */
 int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
 /* Discriminator data-parallel mode for world > 1: 0 = replicated (default: one all-gather of
@@ -147,9 +154,12 @@ int sg_ppo_destroy(sg_ppo *a);
 /* optimizer.param_groups[i]['lr'] = lr  (a2c/utils.py:68-72 update_linear_schedule) */
 int sg_ppo_set_lr(sg_ppo *a, float lr);
 /* PPO.update(rollouts) a2c/algo/ppo.py:65-157 -> out3 = {value_loss, action_loss, dist_entropy}.
- * perms: [ppo_epoch][T*N] int64 = the permutation each epoch's sampler draws
- * (a2c/storage.py:159-162), or NULL -> device-generated from `seed`. */
-int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, uint64_t seed, float out3[3]);
+ * perms: [ppo_epoch][T*N] int64 = the permutation each epoch's sampler draws (a2c/storage.py:159-162) with n_perms =
+ * its element count (checked, as is every index), or NULL (n_perms ignored) -> device-generated from `seed`.
+ * With a communicator of world > 1 an injected permutation is the reference's draw at num_processes = world * N:
+ * [ppo_epoch][T*N*world] ids in its numbering t*(N*world) + rank*N + n, the same array on every rank; each rank takes
+ * the rows of every minibatch it owns (NULL: every rank permutes its own rows and gives T*N/num_mini_batch per step). */
+int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, int64_t n_perms, uint64_t seed, float out3[3]);
 /* Adam state access for checkpoint/parity: m, v flat [n] in state_dict order; *step = t. */
 /* The permutations the last sg_ppo_update consumed ([ppo_epoch][T*N], injected or library-drawn), so a run made
  * with the library's generator can be replayed elsewhere (the role torch.manual_seed plays for the reference). */
@@ -171,20 +181,27 @@ int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
 /* Discriminator.update_gail_dyn(expert_loader, rollouts) a2c/algo/gail.py:154-193, one epoch.
  * batch_size = expert_loader.batch_size; n_d = min(n_expert/batch, T*N/batch) steps.
  * expert_perm[n_expert] (DataLoader shuffle), policy_perm[T*N] (feed_forward_generator),
- * alpha[n_d*batch] (torch.rand per step, a2c/algo/gail.py:72) -- each may be NULL -> `seed`.
+ * alpha[n_d*batch] (torch.rand per step, a2c/algo/gail.py:72) -- each may be NULL -> `seed`; each comes with its
+ * element count (n_expert_perm == n_expert, n_policy_perm == rows the permutation ranges over, n_alpha >= n_d*batch;
+ * ignored for a NULL pointer), and lengths and index ranges are checked before anything is copied to the device.
+ * With a communicator of world > 1 the injected policy_perm is the reference's draw at num_processes = world*N
+ * ([T*N*world] ids in its numbering t*(N*world) + rank*N + n), the same arrays on every rank, in both data-parallel
+ * modes; n_d = min(n_expert/batch, T*N*world/batch).  Sharded mode takes the three arrays together or none.
  * out3 = {mean(gail_loss+grad_pen), mean expert_loss, mean policy_loss}; *n_steps = n_d.
  * n_expert < batch_size is an error (the reference raises on the size mismatch). */
-int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm,
-                            const int64_t *policy_perm, const float *alpha, uint64_t seed,
-                            float out3[3], int *n_steps);
+int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm, int64_t n_expert_perm,
+                            const int64_t *policy_perm, int64_t n_policy_perm, const float *alpha, int64_t n_alpha,
+                            uint64_t seed, float out3[3], int *n_steps);
 /* Discriminator.update(expert_loader, rollouts, obsfilt, is_gail_dyn, a_dim) a2c/algo/gail.py:91-152, one
  * epoch: the same step on caller-assembled policy rows [n_rows, input_dim] (host): (state | action)
  * rows for classic GAIL, (obs_feat | action | next_obs_feat) for is_gail_dyn (a2c/algo/gail.py:102-109).
  * The expert matrix (sg_disc_set_expert) is assembled the same way.  Other arguments as above;
- * policy_perm ranges over n_rows. */
-int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, int batch_size,
-                        const int64_t *expert_perm, const int64_t *policy_perm, const float *alpha,
-                        uint64_t seed, float out3[3], int *n_steps);
+ * policy_perm ranges over n_rows (x world with a communicator).  n_cols = environment columns per time slot when the
+ * rows are a rollout's (t, n) grid (needed to number the union of the ranks' rows as the reference would at
+ * num_processes = world*N), 0 = unstructured rows (the union is numbered rank after rank). */
+int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, int n_cols, int batch_size,
+                        const int64_t *expert_perm, int64_t n_expert_perm, const int64_t *policy_perm, int64_t n_policy_perm,
+                        const float *alpha, int64_t n_alpha, uint64_t seed, float out3[3], int *n_steps);
 /* Discriminator.predict_reward_combined(d_in, gamma, masks, offset) a2c/algo/gail.py:201-210.
  * x[n,F], masks[n] -> reward[n], returns[n]; Discriminator.returns persists inside the handle
  * (first call: returns = reward).  n must stay the same across calls. */

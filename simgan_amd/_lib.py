@@ -42,7 +42,9 @@ PROTOTYPES = {
     "sg_ctx_synchronize": (C.c_int, [H]),
     "sg_ctx_device_info": (C.c_int, [H, C.c_char_p, C.c_int, c_int_p, c_i64_p]),
     "sg_comm_unique_id": (C.c_int, [c_u8_p]),
+    "sg_comm_loopback_id": (C.c_int, [c_u8_p]),
     "sg_ctx_comm_init": (C.c_int, [H, c_u8_p, C.c_int, C.c_int]),
+    "sg_ctx_comm_kind": (C.c_int, [H, c_int_p]),
     "sg_ctx_comm_info": (C.c_int, [H, c_int_p, c_int_p]),
     "sg_ctx_set_disc_dp": (C.c_int, [H, C.c_int]),
     "sg_policy_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
@@ -69,7 +71,7 @@ PROTOTYPES = {
     "sg_ppo_create": (C.c_int, [H, H, C.POINTER(PPOConfig), C.POINTER(H)]),
     "sg_ppo_destroy": (C.c_int, [H]),
     "sg_ppo_set_lr": (C.c_int, [H, C.c_float]),
-    "sg_ppo_update": (C.c_int, [H, H, c_i64_p, C.c_uint64, c_float_p]),
+    "sg_ppo_update": (C.c_int, [H, H, c_i64_p, C.c_int64, C.c_uint64, c_float_p]),
     "sg_ppo_last_perms": (C.c_int, [H, c_i64_p, C.c_int64]),
     "sg_ppo_get_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, c_i64_p]),
     "sg_ppo_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
@@ -81,8 +83,10 @@ PROTOTYPES = {
     "sg_disc_get_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, c_i64_p]),
     "sg_disc_set_adam": (C.c_int, [H, c_float_p, c_float_p, C.c_int64, C.c_int64]),
     "sg_disc_set_expert": (C.c_int, [H, c_float_p, C.c_int64]),
-    "sg_disc_update_gail_dyn": (C.c_int, [H, H, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
-    "sg_disc_update_rows": (C.c_int, [H, c_float_p, C.c_int64, C.c_int, c_i64_p, c_i64_p, c_float_p, C.c_uint64, c_float_p, c_int_p]),
+    "sg_disc_update_gail_dyn": (C.c_int, [H, H, C.c_int, c_i64_p, C.c_int64, c_i64_p, C.c_int64, c_float_p, C.c_int64, C.c_uint64,
+                                          c_float_p, c_int_p]),
+    "sg_disc_update_rows": (C.c_int, [H, c_float_p, C.c_int64, C.c_int, C.c_int, c_i64_p, C.c_int64, c_i64_p, C.c_int64, c_float_p,
+                                      C.c_int64, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
     "sg_disc_predict_prob": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
     "sg_disc_last_draws": (C.c_int, [H, c_i64_p, c_i64_p, c_float_p, c_i64_p]),
@@ -195,8 +199,14 @@ class Context:
         self.rank, self.world = rank, world
         self.disc_sharded = os.environ.get("SG_DISC_DP", "") == "sharded"   # read by sg_ctx_comm_init as well
 
+    def comm_kind(self):
+        """'none' | 'rccl' | 'loopback'"""
+        k = C.c_int(0)
+        check(self.lib.sg_ctx_comm_kind(self.h, C.byref(k)))
+        return ("none", "rccl", "loopback")[k.value]
+
     def comm_info(self):
-        """(rank, world) as RCCL's communicator reports them."""
+        """(rank, world) as the communicator itself reports them."""
         r, w = C.c_int(0), C.c_int(0)
         check(self.lib.sg_ctx_comm_info(self.h, C.byref(r), C.byref(w)))
         return r.value, w.value
@@ -221,4 +231,11 @@ class Context:
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * 128)()
     check(load().sg_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_loopback_id() -> bytes:
+    """Id of a loopback communicator (shared-memory transport between contexts of one host, any devices)."""
+    buf = (C.c_uint8 * 128)()
+    check(load().sg_comm_loopback_id(buf))
     return bytes(buf)

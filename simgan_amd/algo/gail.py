@@ -122,19 +122,13 @@ class Discriminator(object):
             self._expert_id = key
         return int(expert_loader.batch_size)
 
-    def _check_draws(self, B, n_policy_rows, ep, pp, al):
-        """Injected RNG artefacts cross the C ABI as bare pointers: validate their lengths and index ranges here
-        (a short array would be a host out-of-bounds read, a bad index an unchecked device gather)."""
-        n_e = self.n_expert
-        n_d = min(n_e // B, n_policy_rows // B)
-        if ep is not None:
-            assert ep.size == n_e, f"expert_perm: {ep.size} indices for {n_e} expert rows"
-            assert ep.min() >= 0 and ep.max() < n_e, "expert_perm: index out of range"
-        if pp is not None:
-            assert pp.size == n_policy_rows, f"policy_perm: {pp.size} indices for {n_policy_rows} policy rows"
-            assert pp.min() >= 0 and pp.max() < n_policy_rows, "policy_perm: index out of range"
-        if al is not None:
-            assert al.size >= n_d * B, f"alpha: {al.size} draws, the epoch consumes {n_d * B}"
+    @staticmethod
+    def _draw_args(ep, pp, al):
+        """(pointer, count) triples of the injected draws for the C ABI, which checks lengths and index ranges itself
+        (include/simgan_hip.h: sg_disc_update_gail_dyn)."""
+        return (None if ep is None else _lib.i64ptr(ep), 0 if ep is None else ep.size,
+                None if pp is None else _lib.i64ptr(pp), 0 if pp is None else pp.size,
+                None if al is None else _lib.fptr(al), 0 if al is None else al.size)
 
     def last_draws(self):
         """(expert_perm, policy_perm, alpha) the last update epoch consumed (injected or library-drawn)."""
@@ -156,13 +150,11 @@ class Discriminator(object):
         ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
         pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
         al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
-        # replicated data-parallel mode permutes the union of every rank's rows
-        rows_ranged = rollouts.num_steps * rollouts.num_processes * (1 if self.ctx.disc_sharded else self.ctx.world)
-        self._check_draws(B, rows_ranged, ep, pp, al)
+        # world > 1: injected draws are the reference's at num_processes = world * N -- policy_perm ranges over the
+        # union of every rank's rows in the reference's numbering, in both data-parallel modes
         self._calls += 1
         _lib.check(self.lib.sg_disc_update_gail_dyn(
-            self.h, rollouts.h, B, None if ep is None else _lib.i64ptr(ep), None if pp is None else _lib.i64ptr(pp),
-            None if al is None else _lib.fptr(al), (self.seed + self._calls) & (2 ** 64 - 1), out, C.byref(nst)))
+            self.h, rollouts.h, B, *self._draw_args(ep, pp, al), (self.seed + self._calls) & (2 ** 64 - 1), out, C.byref(nst)))
         self.last_n_steps = nst.value
         return float(out[0]), float(out[1]), float(out[2])
 
@@ -197,12 +189,10 @@ class Discriminator(object):
         ep = None if expert_perm is None else _lib.as_i64(expert_perm).reshape(-1)
         pp = None if policy_perm is None else _lib.as_i64(policy_perm).reshape(-1)
         al = None if alpha is None else _lib.as_f32(alpha).reshape(-1)
-        self._check_draws(B, rows.shape[0], ep, pp, al)
         self._calls += 1
         _lib.check(self.lib.sg_disc_update_rows(
-            self.h, _lib.fptr(rows), rows.shape[0], B, None if ep is None else _lib.i64ptr(ep),
-            None if pp is None else _lib.i64ptr(pp), None if al is None else _lib.fptr(al), (self.seed + self._calls) & (2 ** 64 - 1),
-            out, C.byref(nst)))
+            self.h, _lib.fptr(rows), rows.shape[0], int(rollouts.num_processes), B, *self._draw_args(ep, pp, al),
+            (self.seed + self._calls) & (2 ** 64 - 1), out, C.byref(nst)))
         self.last_n_steps = nst.value
         return float(out[0]), float(out[1]), float(out[2])
 

@@ -90,16 +90,16 @@ class PPO():
     def update(self, rollouts, perms=None):
         """a2c/algo/ppo.py:65-157 -> (value_loss_epoch, action_loss_epoch, dist_entropy_epoch).
         `perms` ([ppo_epoch, T*N] int64) injects the samplers' permutations (parity tests);
-        default = the library's counter-based generator."""
+        default = the library's counter-based generator.  With a communicator of world > 1 the injected
+        permutations are the reference's at num_processes = world * N: [ppo_epoch, T*N*world], the same on every rank
+        (include/simgan_hip.h: sg_ppo_update)."""
         rollouts._push([_lib.F_OBS, _lib.F_ACTIONS, _lib.F_VALUE_PREDS, _lib.F_RETURNS, _lib.F_LOGP])
         out = (C.c_float * 3)()
         self._calls += 1
         if perms is not None:
-            perms = _lib.as_i64(perms).reshape(self.ppo_epoch, -1)
-            assert perms.shape[1] == rollouts.num_steps * rollouts.num_processes
-            assert perms.min() >= 0 and perms.max() < perms.shape[1], "perms: row index out of range"
+            perms = _lib.as_i64(perms).reshape(self.ppo_epoch, -1)   # lengths and index ranges are checked behind the C ABI
         _lib.check(self.lib.sg_ppo_update(self.h, rollouts.h, None if perms is None else _lib.i64ptr(perms),
-                                          (self.seed + self._calls) & (2 ** 64 - 1), out))
+                                          0 if perms is None else perms.size, (self.seed + self._calls) & (2 ** 64 - 1), out))
         self._last_perm_shape = (self.ppo_epoch, rollouts.num_steps * rollouts.num_processes)
         return float(out[0]), float(out[1]), float(out[2])
 

@@ -5,9 +5,27 @@
 // dlopen so a single-GPU run has no dependency on it.  Collectives are enqueued on the
 // library's own stream, between the gradient kernels and the optimizer kernels, with no host
 // synchronisation.
+//
+// A second transport, the LOOPBACK communicator, carries the same three collectives between `world` contexts that
+// live on ONE host -- threads of one process or separate processes, on different devices or all on the same one --
+// through a POSIX shared-memory segment (device -> segment, host barrier, every rank sums / concatenates the ranks'
+// slots in rank order, segment -> device).  It exists so that every world > 1 branch of the library (row sharding,
+// global statistics, rank slicing of the discriminator batch, the replicated mode's all-gather) can be executed and
+// checked against the oracle on a one-GPU box, and so that bench.py --gpus N can be self-tested there; it synchronises
+// the stream, so it is never captured into a hipGraph (sg_comm_graph_ok) and it is not a performance path.
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include "sg_common.h"
 
@@ -31,9 +49,167 @@ struct SgRccl {
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 
+// ------------------------------------------------------------------------------------------- loopback transport
+static const char LB_MAGIC[8] = {'S', 'G', 'L', 'O', 'O', 'P', 'B', 'K'};
+
+struct LbHeader {                        // at offset 0 of the shared segment
+    std::atomic<uint32_t> ready;         // 0x5347 once rank 0 has initialised the header
+    std::atomic<uint32_t> arrived;       // barrier: ranks that have arrived in the current generation
+    std::atomic<uint32_t> generation;    // barrier: bumped by the last rank to arrive
+    std::atomic<uint32_t> failed;        // a rank timed out or hit an error: every waiter gives up
+    uint32_t world;
+    uint32_t pad;
+    uint64_t slot_bytes;                 // bytes per (parity, rank) slot
+    std::atomic<uint32_t> attached[64];  // rank -> 1 once it has mapped the segment
+};
+
+struct SgLoopback {
+    LbHeader* hdr = nullptr;
+    uint8_t* data = nullptr;             // [2 parities][world][slot_bytes]
+    size_t map_bytes = 0;
+    uint64_t seq = 0;                    // collectives issued so far (slot parity = seq & 1)
+    void* h_tmp = nullptr;               // private pinned staging for the reduced / gathered result
+    size_t tmp_bytes = 0;
+    double timeout_s = 120.0;
+};
+
 struct SgComm {
     ncclComm_t comm = nullptr;
+    SgLoopback* lb = nullptr;
 };
+
+static double lb_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// Sense-reversing barrier over the segment's atomics (lock-free 32-bit atomics are address-free: valid across processes).
+static int lb_barrier(SgLoopback* lb, const char* what) {
+    LbHeader* h = lb->hdr;
+    const uint32_t gen = h->generation.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == h->world) {
+        h->arrived.store(0, std::memory_order_relaxed);
+        h->generation.fetch_add(1, std::memory_order_acq_rel);
+        return 0;
+    }
+    const double t0 = lb_now();
+    for (unsigned spin = 0; h->generation.load(std::memory_order_acquire) == gen; ++spin) {
+        if (h->failed.load(std::memory_order_relaxed)) { sg_set_error("loopback communicator: a peer rank failed (%s)", what); return -3; }
+        if ((spin & 63) == 63) {
+            sched_yield();
+            if (lb_now() - t0 > lb->timeout_s) {
+                h->failed.store(1, std::memory_order_relaxed);
+                sg_set_error("loopback communicator: %s timed out after %.0f s waiting for the other ranks", what, lb->timeout_s);
+                return -3;
+            }
+        }
+    }
+    return 0;
+}
+
+static void lb_name(const uint8_t id[128], char out[64]) {
+    static const char* hex = "0123456789abcdef";
+    int n = snprintf(out, 64, "/sglb_");
+    for (int i = 8; i < 24; ++i) { out[n++] = hex[id[i] >> 4]; out[n++] = hex[id[i] & 15]; }
+    out[n] = 0;
+}
+
+static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
+    SG_REQUIRE(world <= 64, "loopback communicator: at most 64 ranks");
+    char name[64];
+    lb_name(id, name);
+    if (const char* e = getenv("SG_LOOPBACK_TIMEOUT_S")) { const double v = atof(e); if (v > 0) lb->timeout_s = v; }
+    size_t slot = (size_t)32 << 20;
+    if (const char* e = getenv("SG_LOOPBACK_SLOT_MB")) { const long v = atol(e); if (v > 0) slot = (size_t)v << 20; }
+    const size_t hdr_bytes = 4096;
+    int fd = -1;
+    const double t0 = lb_now();
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        SG_REQUIRE(fd >= 0, "loopback communicator: shm_open(%s) failed: %s", name, strerror(errno));
+        lb->map_bytes = hdr_bytes + 2 * (size_t)world * slot;     // sparse: pages are committed when first touched
+        if (ftruncate(fd, (off_t)lb->map_bytes) != 0) { close(fd); shm_unlink(name); SG_REQUIRE(false, "loopback communicator: ftruncate failed: %s", strerror(errno)); }
+    } else {
+        for (;;) {   // rank 0 creates the segment; wait until it exists and has its final size
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size > hdr_bytes) { lb->map_bytes = (size_t)sb.st_size; break; }
+            if (fd >= 0) { close(fd); fd = -1; }
+            SG_REQUIRE(lb_now() - t0 < lb->timeout_s, "loopback communicator: rank %d never saw rank 0's segment %s", rank, name);
+            usleep(1000);
+        }
+    }
+    void* m = mmap(nullptr, lb->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    SG_REQUIRE(m != MAP_FAILED, "loopback communicator: mmap of %zu bytes failed: %s", lb->map_bytes, strerror(errno));
+    lb->hdr = reinterpret_cast<LbHeader*>(m);
+    lb->data = reinterpret_cast<uint8_t*>(m) + hdr_bytes;
+    if (rank == 0) {
+        lb->hdr->world = (uint32_t)world;
+        lb->hdr->slot_bytes = slot;
+        lb->hdr->ready.store(0x5347, std::memory_order_release);
+    } else {
+        while (lb->hdr->ready.load(std::memory_order_acquire) != 0x5347) {
+            SG_REQUIRE(lb_now() - t0 < lb->timeout_s, "loopback communicator: rank 0 never initialised the segment");
+            usleep(200);
+        }
+        SG_REQUIRE(lb->hdr->world == (uint32_t)world, "loopback communicator: rank 0 created a world of %u, rank %d was given %d",
+                   lb->hdr->world, rank, world);
+    }
+    SG_REQUIRE(lb->hdr->attached[rank].exchange(1) == 0, "loopback communicator: rank %d attached twice", rank);
+    SG_TRY(lb_barrier(lb, "communicator set-up"));
+    if (rank == 0) shm_unlink(name);   // every rank has mapped it: the name can go, the memory lives until the last munmap
+    return 0;
+}
+
+static int lb_tmp(SgLoopback* lb, size_t bytes) {
+    if (bytes <= lb->tmp_bytes) return 0;
+    if (lb->h_tmp) SG_CHECK(hipHostFree(lb->h_tmp));
+    lb->tmp_bytes = bytes + bytes / 2 + 4096;
+    SG_CHECK(hipHostMalloc(&lb->h_tmp, lb->tmp_bytes, hipHostMallocDefault));
+    return 0;
+}
+
+// One collective over the segment.  op 0: element-wise sum (rank order 0..world-1, the same on every rank, so all ranks
+// hold bit-identical results, like a ring all-reduce); op 1: concatenation in rank order.  esize 4 (float) or 8 (double).
+static int lb_collective(sg_ctx* ctx, int op, const void* dev_in, void* dev_out, size_t n, int esize) {
+    SgLoopback* lb = ctx->comm->lb;
+    const int world = ctx->world, rank = ctx->rank;
+    const size_t slot = lb->hdr->slot_bytes, chunk_elems = slot / (size_t)esize;
+    SG_CHECK(hipSetDevice(ctx->device));
+    SG_REQUIRE(n > 0, "loopback communicator: empty collective");
+    for (size_t off = 0; off < n; off += chunk_elems) {
+        const size_t cnt = n - off < chunk_elems ? n - off : chunk_elems, bytes = cnt * (size_t)esize;
+        uint8_t* base = lb->data + (lb->seq & 1) * (size_t)world * slot;
+        lb->seq += 1;
+        SG_CHECK(hipMemcpyAsync(base + (size_t)rank * slot, (const uint8_t*)dev_in + off * esize, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        // Double-buffered slots: a rank overwrites parity p again only after the barrier of the collective in between,
+        // i.e. after every rank has finished reading the previous contents -- one barrier per collective is enough.
+        SG_TRY(lb_barrier(lb, op == 0 ? "all-reduce" : "all-gather"));
+        if (op == 0) {
+            SG_TRY(lb_tmp(lb, bytes));
+            if (esize == 4) {
+                float* acc = (float*)lb->h_tmp;
+                memcpy(acc, base, bytes);
+                for (int r = 1; r < world; ++r) { const float* s = (const float*)(base + (size_t)r * slot); for (size_t i = 0; i < cnt; ++i) acc[i] += s[i]; }
+            } else {
+                double* acc = (double*)lb->h_tmp;
+                memcpy(acc, base, bytes);
+                for (int r = 1; r < world; ++r) { const double* s = (const double*)(base + (size_t)r * slot); for (size_t i = 0; i < cnt; ++i) acc[i] += s[i]; }
+            }
+            SG_CHECK(hipMemcpyAsync((uint8_t*)dev_out + off * esize, lb->h_tmp, bytes, hipMemcpyHostToDevice, ctx->stream));
+            SG_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            // rank r's chunk [off, off+cnt) of its n elements lands at out[r*n + off]
+            for (int r = 0; r < world; ++r)
+                SG_CHECK(hipMemcpyAsync((uint8_t*)dev_out + ((size_t)r * n + off) * esize, base + (size_t)r * slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+            SG_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return 0;
+}
 
 static SgRccl g_rccl;
 
@@ -78,12 +254,49 @@ extern "C" int sg_comm_unique_id(uint8_t id[128]) {
     return 0;
 }
 
+// An id for the loopback transport: the magic tag + 16 random bytes that name the shared segment.  Drawn on rank 0 and
+// handed to every rank exactly like an RCCL id; sg_ctx_comm_init recognises the tag.
+extern "C" int sg_comm_loopback_id(uint8_t id[128]) {
+    SG_REQUIRE(id, "sg_comm_loopback_id: id is NULL");
+    memset(id, 0, 128);
+    memcpy(id, LB_MAGIC, 8);
+    FILE* f = fopen("/dev/urandom", "rb");
+    const bool ok = f && fread(id + 8, 1, 16, f) == 16;
+    if (f) fclose(f);
+    if (!ok) {   // no urandom: pid + clock
+        uint64_t v[2] = {(uint64_t)getpid() * 0x9E3779B97F4A7C15ull, (uint64_t)(lb_now() * 1e9)};
+        memcpy(id + 8, v, 16);
+    }
+    return 0;
+}
+
+static void comm_common_flags(sg_ctx* ctx, int world) {
+    // SG_COMM_ALWAYS=1 keeps the collectives in the launch sequence even for a single rank (where
+    // they are the identity): the 1-GPU self-test of the RCCL path (tests/test_gpu_comm.py)
+    const char* always = getenv("SG_COMM_ALWAYS");
+    ctx->use_comm = world > 1 || (always && always[0] == '1');
+    const char* dp = getenv("SG_DISC_DP");
+    ctx->disc_sharded = dp && strcmp(dp, "sharded") == 0;
+}
+
 extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, int world) {
     SG_REQUIRE(ctx && id, "sg_ctx_comm_init: NULL argument");
     SG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "sg_ctx_comm_init: bad rank %d / world %d", rank, world);
     SG_REQUIRE(!ctx->comm, "sg_ctx_comm_init: communicator already initialised");
-    SG_TRY(rccl_load());
     SG_CHECK(hipSetDevice(ctx->device));
+    if (memcmp(id, LB_MAGIC, 8) == 0) {   // loopback transport (sg_comm_loopback_id)
+        SgLoopback* lb = new SgLoopback();
+        const int rc = lb_open(lb, id, rank, world);
+        if (rc != 0) { if (lb->hdr) munmap(lb->hdr, lb->map_bytes); delete lb; return rc; }
+        SgComm* c = new SgComm();
+        c->lb = lb;
+        ctx->comm = c;
+        ctx->rank = rank;
+        ctx->world = world;
+        comm_common_flags(ctx, world);
+        return 0;
+    }
+    SG_TRY(rccl_load());
     ncclUniqueId u;
     memcpy(u.internal, id, 128);
     SgComm* c = new SgComm();
@@ -91,12 +304,7 @@ extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, in
     ctx->comm = c;
     ctx->rank = rank;
     ctx->world = world;
-    // SG_COMM_ALWAYS=1 keeps the collectives in the launch sequence even for a single rank (where
-    // they are the identity): the 1-GPU self-test of the RCCL path (tests/test_gpu_comm.py)
-    const char* always = getenv("SG_COMM_ALWAYS");
-    ctx->use_comm = world > 1 || (always && always[0] == '1');
-    const char* dp = getenv("SG_DISC_DP");
-    ctx->disc_sharded = dp && strcmp(dp, "sharded") == 0;
+    comm_common_flags(ctx, world);
     // One tiny all-reduce now: RCCL sets up its channels and proxy connections lazily on the first collective, which must
     // not happen inside a stream capture (the updates capture their collectives into hipGraphs).
     float* warm = nullptr;
@@ -111,6 +319,12 @@ extern "C" int sg_ctx_comm_info(sg_ctx* ctx, int* rank, int* world) {
     SG_REQUIRE(ctx, "sg_ctx_comm_info: ctx is NULL");
     if (rank) *rank = ctx->rank;
     if (world) *world = ctx->world;
+    if (ctx->comm && ctx->comm->lb) {   // loopback: the world rank 0 wrote into the segment, and this rank's attach mark
+        const LbHeader* h = ctx->comm->lb->hdr;
+        SG_REQUIRE((int)h->world == ctx->world && h->attached[ctx->rank].load() == 1,
+                   "loopback segment reports a world of %u, the context was initialised as %d of %d", h->world, ctx->rank, ctx->world);
+        return 0;
+    }
     if (ctx->comm) {   // what the communicator itself reports (ncclCommUserRank / ncclCommCount), not what it was asked for
         int r = -1, n = -1;
         SG_NCCL(g_rccl.CommUserRank(ctx->comm->comm, &r));
@@ -129,20 +343,46 @@ extern "C" int sg_ctx_set_disc_dp(sg_ctx* ctx, int sharded) {
     return 0;
 }
 
+// 1: RCCL (collectives are stream operations and can be captured into a hipGraph), 0: loopback (synchronises the stream)
+int sg_comm_graph_ok(const sg_ctx* ctx) { return !(ctx->comm && ctx->comm->lb); }
+
+// 0: none, 1: RCCL, 2: loopback
+extern "C" int sg_ctx_comm_kind(sg_ctx* ctx, int* kind) {
+    SG_REQUIRE(ctx && kind, "sg_ctx_comm_kind: NULL argument");
+    *kind = !ctx->comm ? 0 : ctx->comm->lb ? 2 : 1;
+    return 0;
+}
+
+void sg_comm_destroy(sg_ctx* ctx) {
+    if (!ctx->comm) return;
+    if (ctx->comm->lb) {
+        SgLoopback* lb = ctx->comm->lb;
+        if (lb->h_tmp) (void)hipHostFree(lb->h_tmp);
+        if (lb->hdr) munmap(lb->hdr, lb->map_bytes);
+        delete lb;
+    }
+    // (an RCCL communicator is left to process exit: ncclCommDestroy blocks when a peer rank has already gone)
+    delete ctx->comm;
+    ctx->comm = nullptr;
+}
+
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n) {
     SG_REQUIRE(ctx->comm, "all-reduce requested but no communicator (call sg_ctx_comm_init)");
+    if (ctx->comm->lb) return lb_collective(ctx, 0, dev, dev, (size_t)n, 4);
     SG_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat32, ncclSum, ctx->comm->comm, ctx->stream));
     return 0;
 }
 
 int sg_comm_allreduce_f64(sg_ctx* ctx, double* dev, int64_t n) {
     SG_REQUIRE(ctx->comm, "all-reduce requested but no communicator (call sg_ctx_comm_init)");
+    if (ctx->comm->lb) return lb_collective(ctx, 0, dev, dev, (size_t)n, 8);
     SG_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, ctx->comm->comm, ctx->stream));
     return 0;
 }
 
 int sg_comm_allgather_f32(sg_ctx* ctx, const float* dev_in, float* dev_out, int64_t n_per_rank) {
     SG_REQUIRE(ctx->comm, "all-gather requested but no communicator (call sg_ctx_comm_init)");
+    if (ctx->comm->lb) return lb_collective(ctx, 1, dev_in, dev_out, (size_t)n_per_rank, 4);
     SG_NCCL(g_rccl.AllGather(dev_in, dev_out, (size_t)n_per_rank, ncclFloat32, ctx->comm->comm, ctx->stream));
     return 0;
 }

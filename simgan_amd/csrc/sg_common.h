@@ -253,7 +253,9 @@ static inline int sg_try_capture(sg_ctx* ctx, hipGraphExec_t* exec, F&& enqueue)
     return 0;
 }
 
-// RCCL (sg_comm.cpp)
+// collectives (sg_comm.cpp): RCCL, or the one-host loopback transport
+int sg_comm_graph_ok(const sg_ctx* ctx);   // 1: the collectives are stream operations that a hipGraph capture records
+void sg_comm_destroy(sg_ctx* ctx);
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n);
 int sg_comm_allreduce_f64(sg_ctx* ctx, double* dev, int64_t n);
 int sg_comm_allgather_f32(sg_ctx* ctx, const float* dev_in, float* dev_out, int64_t n_per_rank);

@@ -50,6 +50,7 @@ extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    sg_comm_destroy(ctx);
     for (auto& s : ctx->prof)
         for (auto& p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -146,6 +147,7 @@ SgEv sg_prof_events(sg_ctx* ctx, int which) {
 
 static void prof_drain(sg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    sg_comm_destroy(ctx);
     for (auto& s : ctx->prof) {
         for (auto& p : s.pending) {
             float ms = 0.f;

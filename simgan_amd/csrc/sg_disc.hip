@@ -349,15 +349,35 @@ static int ensure_cap(T** ptr, int64_t* cap, int64_t need, hipStream_t stream) {
     return 0;
 }
 
-// One epoch of discriminator steps on `rows_local` (device, [TN_loc, F]: this rank's policy rows).
-static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc, int batch_size,
-                            const int64_t* expert_perm, const int64_t* policy_perm, const float* alpha,
-                            uint64_t seed, float out3[3], int* n_steps) {
+// Injected draws arrive as host arrays with explicit element counts: lengths are checked against what the epoch
+// consumes and every index against the range it addresses BEFORE anything is copied to the device (a short array would be
+// a host out-of-bounds read, a bad index an unchecked device gather).
+static int check_index_array(const char* who, const char* name, const int64_t* a, int64_t n, int64_t need, int64_t limit) {
+    SG_REQUIRE(n == need, "%s: %s holds %lld indices, the epoch needs exactly %lld", who, name, (long long)n, (long long)need);
+    for (int64_t i = 0; i < n; ++i)
+        SG_REQUIRE(a[i] >= 0 && a[i] < limit, "%s: %s[%lld] = %lld is outside [0, %lld)", who, name, (long long)i, (long long)a[i], (long long)limit);
+    return 0;
+}
+
+// One epoch of discriminator steps on `rows_local` (device, [TN_loc, F]: this rank's policy rows; n_cols = environment
+// columns per time slot when the rows are a rollout's (t, n) grid, 0 when they are unstructured).
+//
+// Row numbering for world > 1.  The reference is single-process: at num_processes = world * N its flattened row id is
+// t * (world*N) + n_global (a2c/storage.py:168-185), with rank r owning columns [r*N, (r+1)*N).  Every INJECTED policy
+// permutation is in that global numbering, in both data-parallel modes, so the reference's own draws at the global size
+// reproduce the reference's result; the library's own generator draws in the same numbering in replicated mode and, in
+// sharded mode, one local permutation per rank (each rank contributes batch/world rows to every step).
+static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc, int n_cols, int batch_size,
+                            const int64_t* expert_perm, int64_t n_expert_perm, const int64_t* policy_perm, int64_t n_policy_perm,
+                            const float* alpha, int64_t n_alpha, uint64_t seed, float out3[3], int* n_steps) {
     sg_ctx* ctx = d->ctx;
     const SgDiscDesc& dd = d->desc;
     const int rowF = dd.F;
+    const char* who = "sg_disc_update_gail_dyn";
     SG_REQUIRE(d->d_expert, "sg_disc_update_gail_dyn: no expert data (call sg_disc_set_expert first)");
     SG_REQUIRE(batch_size > 0, "sg_disc_update_gail_dyn: batch_size must be positive");
+    SG_REQUIRE(n_cols >= 0 && (n_cols == 0 || TN_loc % n_cols == 0), "sg_disc_update_gail_dyn: %lld rows are not a grid of %d columns",
+               (long long)TN_loc, n_cols);
     // Data-parallel modes (world > 1).  "replicated" (default): the discriminator is replicated; once
     // per call the ranks all-gather their next_obs_feat rows, then every rank runs the SAME sequence of
     // full-batch steps on the global row set (same seeds, deterministic kernels => identical replicas),
@@ -367,20 +387,31 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int world = ctx->world;
     const bool replicated = ctx->use_comm && !ctx->disc_sharded;
     const bool sharded = ctx->use_comm && ctx->disc_sharded;
-    const int split = sharded ? world : 1;
+    // sharded mode with injected draws: rank r takes the batch positions whose policy row it owns (all three row kinds
+    // of that position: expert, policy, mixup), so the counts per step are uneven -- the parity form of SURVEY.md 8(e)
+    const bool owned = sharded && world > 1 && policy_perm != nullptr;
+    SG_REQUIRE(!owned || (expert_perm && alpha), "sg_disc_update_gail_dyn: sharded data-parallel mode takes injected draws all "
+               "together (expert_perm, policy_perm and alpha), or none of them");
+    SG_REQUIRE(!(sharded && world > 1 && !policy_perm && (expert_perm || alpha)), "sg_disc_update_gail_dyn: sharded data-parallel "
+               "mode takes injected draws all together (expert_perm, policy_perm and alpha), or none of them");
+    const int split = (sharded && !owned) ? world : 1;
     SG_REQUIRE(batch_size % split == 0, "sg_disc_update_gail_dyn: batch_size %d must divide by world size %d", batch_size, world);
-    const int B_loc = batch_size / split;
     // the reference's alpha*expert + (1-alpha)*policy raises on a size mismatch when the loader
     // yields a short batch (a2c/algo/gail.py:75)
     SG_REQUIRE(d->n_expert >= batch_size, "The size of tensor a (%lld) must match the size of tensor b (%d) at "
                "non-singleton dimension 0 (expert rows < gail batch size)", (long long)d->n_expert, batch_size);
     SG_CHECK(hipSetDevice(ctx->device));
-    const int64_t TN = replicated ? TN_loc * world : TN_loc;     // rows the policy permutation ranges over
+    const int64_t TN_glob = TN_loc * (ctx->use_comm ? world : 1);
+    const int64_t TN = (replicated || owned) ? TN_glob : TN_loc;   // rows the policy permutation ranges over
     const int64_t n_e = d->n_expert / batch_size;   // drop_last (or exactly one full batch)
-    const int64_t n_p = TN / B_loc;                 // sharded: local rows contribute batch/world per step
+    const int64_t n_p = (sharded && !owned) ? TN_loc / (batch_size / split) : TN / batch_size;
     const int n_d = (int)(n_e < n_p ? n_e : n_p);
-    SG_REQUIRE(n_d > 0, "sg_disc_update_gail_dyn: rollout (%lld rows) smaller than one batch (%d)", (long long)TN, B_loc);
+    SG_REQUIRE(n_d > 0, "sg_disc_update_gail_dyn: rollout (%lld rows) smaller than one batch (%d)", (long long)TN, batch_size / split);
     if (n_steps) *n_steps = n_d;
+    if (expert_perm) SG_TRY(check_index_array(who, "expert_perm", expert_perm, n_expert_perm, d->n_expert, d->n_expert));
+    if (policy_perm) SG_TRY(check_index_array(who, "policy_perm", policy_perm, n_policy_perm, TN, TN));
+    if (alpha) SG_REQUIRE(n_alpha >= (int64_t)n_d * batch_size, "sg_disc_update_gail_dyn: alpha holds %lld draws, the epoch consumes %lld",
+                          (long long)n_alpha, (long long)n_d * batch_size);
     const float* next_feat = rows_local;
     if (replicated) {
         SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * rowF, ctx->stream));
@@ -388,23 +419,65 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         next_feat = d->d_feat_all;
     }
 
+    // per-step geometry: rows [off[k], off[k] + cnt[k]) of the epoch's row copies; B_loc = the largest count (it sizes the
+    // launch and the scratch; rows past a step's count are masked inside the kernels)
+    std::vector<int> step_cnt(n_d), step_off(n_d + 1);
+    std::vector<int64_t> ep_own, pp_own;
+    std::vector<float> al_own;
+    int B_loc = batch_size / split;
+    if (owned) {
+        const int64_t Ng = n_cols ? (int64_t)n_cols * world : 0;
+        B_loc = 1;
+        for (int k = 0; k < n_d; ++k) {
+            step_off[k] = (int)pp_own.size();
+            for (int i = 0; i < batch_size; ++i) {
+                const int64_t g = policy_perm[(size_t)k * batch_size + i];
+                int64_t owner, local;
+                if (Ng) { const int64_t t = g / Ng, c = g - t * Ng; owner = c / n_cols; local = t * n_cols + (c - owner * n_cols); }
+                else { owner = g / TN_loc; local = g - owner * TN_loc; }
+                if (owner != ctx->rank) continue;
+                pp_own.push_back(local);
+                ep_own.push_back(expert_perm[(size_t)k * batch_size + i]);
+                al_own.push_back(alpha[(size_t)k * batch_size + i]);
+            }
+            step_cnt[k] = (int)pp_own.size() - step_off[k];
+            if (step_cnt[k] > B_loc) B_loc = step_cnt[k];
+        }
+        step_off[n_d] = (int)pp_own.size();
+    } else {
+        for (int k = 0; k <= n_d; ++k) { step_off[k] = k * B_loc; if (k < n_d) step_cnt[k] = B_loc; }
+    }
+    const int64_t rows_total = step_off[n_d];
+
     SG_TRY(ensure_cap(&d->d_eperm, &d->eperm_cap, d->n_expert, ctx->stream));
     SG_TRY(ensure_cap(&d->d_pperm, &d->pperm_cap, TN, ctx->stream));
     SG_TRY(ensure_cap(&d->d_alpha, &d->alpha_cap, (int64_t)n_d * batch_size, ctx->stream));
-    SG_TRY(ensure_cap(&d->d_erows, &d->erows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // +1: the last step's
-    SG_TRY(ensure_cap(&d->d_prows, &d->prows_cap, (int64_t)(n_d + 1) * B_loc * rowF, ctx->stream));   // "next" pointers stay in range
+    SG_TRY(ensure_cap(&d->d_erows, &d->erows_cap, (rows_total + B_loc) * rowF, ctx->stream));   // + one step: the last step's
+    SG_TRY(ensure_cap(&d->d_prows, &d->prows_cap, (rows_total + B_loc) * rowF, ctx->stream));   // "next" pointers stay in range
     d->rng_calls += 1;
     d->last_draws[0] = d->n_expert; d->last_draws[1] = TN; d->last_draws[2] = (int64_t)n_d * batch_size;
-    // expert permutation / alpha are GLOBAL (identical on every rank); the policy permutation is per rank
-    if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
-    else SG_TRY(sg_fill_perm(ctx, d->d_eperm, d->n_expert, seed, 0xE0000000ull + d->rng_calls));
-    if (policy_perm) SG_CHECK(hipMemcpyAsync(d->d_pperm, policy_perm, sizeof(int64_t) * TN, hipMemcpyHostToDevice, ctx->stream));
-    else SG_TRY(sg_fill_perm(ctx, d->d_pperm, TN, seed, 0xF0000000ull + d->rng_calls * 1024 + (uint64_t)(sharded ? ctx->rank : 0)));
-    if (alpha) SG_CHECK(hipMemcpyAsync(d->d_alpha, alpha, sizeof(float) * (size_t)n_d * batch_size, hipMemcpyHostToDevice, ctx->stream));
-    else {
-        const int64_t na = (int64_t)n_d * batch_size;
-        hipLaunchKernelGGL(k_fill_alpha, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream, d->d_alpha, na,
-                           seed, 0xA1000000ull + d->rng_calls);
+    if (owned) {
+        // the device arrays hold this rank's share of the draws, in consumption order (sg_disc_last_draws: not available)
+        d->last_draws[0] = d->last_draws[1] = d->last_draws[2] = 0;
+        if (rows_total) {
+            SG_CHECK(hipMemcpyAsync(d->d_eperm, ep_own.data(), sizeof(int64_t) * rows_total, hipMemcpyHostToDevice, ctx->stream));
+            SG_CHECK(hipMemcpyAsync(d->d_pperm, pp_own.data(), sizeof(int64_t) * rows_total, hipMemcpyHostToDevice, ctx->stream));
+            SG_CHECK(hipMemcpyAsync(d->d_alpha, al_own.data(), sizeof(float) * rows_total, hipMemcpyHostToDevice, ctx->stream));
+            SG_CHECK(hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope with this call
+        }
+    } else {
+        // expert permutation / alpha are GLOBAL (identical on every rank); the library-drawn policy permutation is per rank
+        // in sharded mode
+        if (expert_perm) SG_CHECK(hipMemcpyAsync(d->d_eperm, expert_perm, sizeof(int64_t) * d->n_expert, hipMemcpyHostToDevice, ctx->stream));
+        else SG_TRY(sg_fill_perm(ctx, d->d_eperm, d->n_expert, seed, 0xE0000000ull + d->rng_calls));
+        if (policy_perm) SG_CHECK(hipMemcpyAsync(d->d_pperm, policy_perm, sizeof(int64_t) * TN, hipMemcpyHostToDevice, ctx->stream));
+        else SG_TRY(sg_fill_perm(ctx, d->d_pperm, TN, seed, 0xF0000000ull + d->rng_calls * 1024 + (uint64_t)(sharded ? ctx->rank : 0)));
+        if (alpha) SG_CHECK(hipMemcpyAsync(d->d_alpha, alpha, sizeof(float) * (size_t)n_d * batch_size, hipMemcpyHostToDevice, ctx->stream));
+        else {
+            const int64_t na = (int64_t)n_d * batch_size;
+            hipLaunchKernelGGL(k_fill_alpha, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream, d->d_alpha, na,
+                               seed, 0xA1000000ull + d->rng_calls);
+        }
     }
 
     const int G = (B_loc + 15) / 16;
@@ -454,31 +527,39 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     // host thread can no longer starve the GPU in the middle of an epoch.
     auto enqueue_epoch = [&]() -> int {
         hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, ctx->stream, d->d_loss_acc, 3);
-        {   // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch (sharded mode)
+        {
             EpochRowsArgs er;
             er.expert = d->d_expert; er.feat = a.next_feat; er.eperm = d->d_eperm; er.pperm = d->d_pperm;
-            er.erows = d->d_erows; er.prows = d->d_prows; er.n_d = n_d; er.B_loc = B_loc; er.batch_size = batch_size;
-            er.roff = sharded ? ctx->rank * B_loc : 0; er.F = dd.F;
-            hipLaunchKernelGGL(k_disc_epoch_rows, dim3(2048), dim3(256), 0, ctx->stream, er);
+            er.erows = d->d_erows; er.prows = d->d_prows; er.F = dd.F;
+            if (owned) {   // the draws were compacted to this rank's share on the host: one run of rows_total rows
+                er.n_d = 1; er.B_loc = (int)rows_total; er.batch_size = (int)rows_total; er.roff = 0;
+            } else {       // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch (sharded mode)
+                er.n_d = n_d; er.B_loc = B_loc; er.batch_size = batch_size; er.roff = sharded ? ctx->rank * B_loc : 0;
+            }
+            // replicated mode: the all-gathered union is rank-major, the permutation is in the reference's (t, n_global) order
+            er.remap_N = (replicated && world > 1) ? n_cols : 0; er.remap_W = world; er.TN_loc = TN_loc;
+            if (rows_total) hipLaunchKernelGGL(k_disc_epoch_rows, dim3(2048), dim3(256), 0, ctx->stream, er);
         }
         for (int k = 0; k < n_d; ++k) {
-            // rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
-            const size_t roff = sharded ? (size_t)ctx->rank * B_loc : 0;
-            a.eperm = d->d_eperm + (size_t)k * batch_size + roff;
-            a.alpha = d->d_alpha + (size_t)k * batch_size + roff;
-            a.pperm = d->d_pperm + (size_t)k * B_loc;
+            // uniform: rank r takes rows [r*B_loc, (r+1)*B_loc) of the global expert batch and of alpha
+            const size_t al_off = owned ? (size_t)step_off[k] : (size_t)k * batch_size + (sharded ? (size_t)ctx->rank * B_loc : 0);
+            const size_t al_next = owned ? (size_t)step_off[k + 1] : al_off + batch_size;
+            a.eperm = d->d_eperm + al_off;
+            a.alpha = d->d_alpha + al_off;
+            a.pperm = d->d_pperm + (size_t)step_off[k];
+            a.B = step_cnt[k];
             a.ops = stacks[k & 1];
             wa.ops = a.ops;
             PregatherArgs pg;
-            pg.B = B_loc; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp; pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st;
-            const size_t step_rows = (size_t)B_loc * dd.F;
+            pg.B = step_cnt[k]; pg.G = G; pg.F = dd.F; pg.Fp = dd.Fp; pg.ldF = dd.ldF; pg.Hp = dd.Hp; pg.st = a.st;
             wa.k1 = k + 1;
             if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
                 pg.erows = d->d_erows; pg.prows = d->d_prows; pg.alpha = a.alpha; pg.ops = a.ops;
                 hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
             }
-            pg.erows = d->d_erows + (size_t)(k + 1) * step_rows; pg.prows = d->d_prows + (size_t)(k + 1) * step_rows;
-            pg.alpha = a.alpha + batch_size;
+            pg.B = k + 1 < n_d ? step_cnt[k + 1] : 0;
+            pg.erows = d->d_erows + (size_t)step_off[k + 1] * dd.F; pg.prows = d->d_prows + (size_t)step_off[k + 1] * dd.F;
+            pg.alpha = d->d_alpha + al_next;
             pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
             wa.next = pg;
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
@@ -498,12 +579,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     // SG_DISC_GRAPH_COMM=0 or the RCCL build refuses the capture.
     const char* genv = getenv("SG_DISC_GRAPH");
     const char* gcenv = getenv("SG_DISC_GRAPH_COMM");
-    const bool comm_ok = !sharded || (!d->graph_refused && !(gcenv && !strcmp(gcenv, "0")));
-    bool use_graph = comm_ok && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
+    const bool comm_ok = !sharded || (!d->graph_refused && sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0")));
+    bool use_graph = comm_ok && !owned && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
     if (use_graph) {
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
-                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size, (uint64_t)thin | (sharded ? 2u : 0u), (uint64_t)ops_f,
+                                  (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size,
+                                  (uint64_t)thin | (sharded ? 2u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
@@ -533,25 +615,26 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     return 0;
 }
 
-extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm,
-                                       const int64_t* policy_perm, const float* alpha, uint64_t seed,
-                                       float out3[3], int* n_steps) {
+extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm, int64_t n_expert_perm,
+                                       const int64_t* policy_perm, int64_t n_policy_perm, const float* alpha, int64_t n_alpha,
+                                       uint64_t seed, float out3[3], int* n_steps) {
     SG_REQUIRE(d && r && out3, "sg_disc_update_gail_dyn: NULL argument");
     SG_REQUIRE(r->F == d->desc.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
     // policy rows = next_obs_feat = obs_feat[1:]   (a2c/storage.py:172, a2c/algo/gail.py:165)
-    return disc_update_core(d, r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F, (int64_t)r->T * r->N, batch_size,
-                            expert_perm, policy_perm, alpha, seed, out3, n_steps);
+    return disc_update_core(d, r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F, (int64_t)r->T * r->N, r->N, batch_size,
+                            expert_perm, n_expert_perm, policy_perm, n_policy_perm, alpha, n_alpha, seed, out3, n_steps);
 }
 
-extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t n_rows, int batch_size,
-                                   const int64_t* expert_perm, const int64_t* policy_perm, const float* alpha,
-                                   uint64_t seed, float out3[3], int* n_steps) {
+extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t n_rows, int n_cols, int batch_size,
+                                   const int64_t* expert_perm, int64_t n_expert_perm, const int64_t* policy_perm, int64_t n_policy_perm,
+                                   const float* alpha, int64_t n_alpha, uint64_t seed, float out3[3], int* n_steps) {
     SG_REQUIRE(d && policy_rows && out3 && n_rows > 0, "sg_disc_update_rows: bad argument");
     sg_ctx* ctx = d->ctx;
     SG_CHECK(hipSetDevice(ctx->device));
     SG_TRY(ensure_cap(&d->d_rows, &d->rows_cap, n_rows * d->desc.F, ctx->stream));
     SG_CHECK(hipMemcpyAsync(d->d_rows, policy_rows, sizeof(float) * (size_t)n_rows * d->desc.F, hipMemcpyHostToDevice, ctx->stream));
-    return disc_update_core(d, d->d_rows, n_rows, batch_size, expert_perm, policy_perm, alpha, seed, out3, n_steps);
+    return disc_update_core(d, d->d_rows, n_rows, n_cols, batch_size, expert_perm, n_expert_perm, policy_perm, n_policy_perm, alpha,
+                            n_alpha, seed, out3, n_steps);
 }
 
 static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward, int prob = 0) {

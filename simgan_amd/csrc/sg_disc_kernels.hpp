@@ -114,6 +114,11 @@ struct EpochRowsArgs {
     const int64_t *eperm, *pperm;
     float *erows, *prows;
     int n_d, B_loc, batch_size, roff, F;
+    // replicated data-parallel mode: `feat` is the all-gathered union, rank-major ([world][TN_loc] rows), while the
+    // permutation is in the reference's numbering at num_processes = world * N: row t * (N*world) + rank * N + n
+    // (a2c/storage.py:168-185).  remap_N = N (0: the permutation indexes `feat` directly), remap_W = world.
+    int remap_N, remap_W;
+    int64_t TN_loc;
 };
 __global__ __launch_bounds__(256) void k_disc_epoch_rows(EpochRowsArgs a) {
     const int64_t total = (int64_t)a.n_d * a.B_loc * a.F;
@@ -122,7 +127,12 @@ __global__ __launch_bounds__(256) void k_disc_epoch_rows(EpochRowsArgs a) {
         const int c = (int)(i - row * a.F);
         const int k = (int)(row / a.B_loc), b = (int)(row - (int64_t)k * a.B_loc);
         a.erows[i] = a.expert[(size_t)a.eperm[(size_t)k * a.batch_size + a.roff + b] * a.F + c];
-        a.prows[i] = a.feat[(size_t)a.pperm[(size_t)k * a.B_loc + b] * a.F + c];
+        int64_t g = a.pperm[(size_t)k * a.B_loc + b];
+        if (a.remap_N) {
+            const int64_t Ng = (int64_t)a.remap_N * a.remap_W, t = g / Ng, cg = g - t * Ng, rk = cg / a.remap_N;
+            g = rk * a.TN_loc + t * a.remap_N + (cg - rk * a.remap_N);
+        }
+        a.prows[i] = a.feat[(size_t)g * a.F + c];
     }
 }
 

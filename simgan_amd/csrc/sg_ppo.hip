@@ -199,7 +199,7 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     return 0;
 }
 
-extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uint64_t seed, float out3[3]) {
+extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int64_t n_perms, uint64_t seed, float out3[3]) {
     SG_REQUIRE(a && r && out3, "sg_ppo_update: NULL argument");
     sg_ctx* ctx = a->ctx;
     const SgPolicyDesc& d = a->policy->desc;
@@ -211,8 +211,50 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     SG_REQUIRE(TN >= M, "PPO requires the number of processes (%d) * number of steps (%d) = %lld to be greater than "
                "or equal to the number of PPO mini batches (%d).", r->N, r->T, (long long)TN, M);
     SG_CHECK(hipSetDevice(ctx->device));
-    const int mb = (int)(TN / M);
     const int world = ctx->world;
+    // Minibatch geometry.  Single rank, or the library's own generator: every rank permutes its own TN rows and gives
+    // TN / M of them to each step.  World > 1 with INJECTED permutations ("owned" mode, the parity form of SURVEY.md 8(e)):
+    // the permutations are the reference's own draws at num_processes = world * N -- [E][TN * world] ids in its numbering
+    // t * (N * world) + rank * N + n (a2c/storage.py:159-185) -- and rank r takes, of every minibatch, the rows it owns,
+    // so the counts per step are uneven; row groups past a step's count are masked inside the kernels.
+    const bool owned = perms != nullptr && ctx->use_comm && world > 1;
+    const int64_t TN_perm = owned ? TN * world : TN;
+    if (perms) {
+        SG_REQUIRE(n_perms == (int64_t)E * TN_perm, "sg_ppo_update: perms holds %lld indices, %d epochs x %lld rows need %lld",
+                   (long long)n_perms, E, (long long)TN_perm, (long long)E * TN_perm);
+        for (int64_t i = 0; i < n_perms; ++i)
+            SG_REQUIRE(perms[i] >= 0 && perms[i] < TN_perm, "sg_ppo_update: perms[%lld] = %lld is outside [0, %lld)", (long long)i,
+                       (long long)perms[i], (long long)TN_perm);
+    }
+    std::vector<int> step_cnt((size_t)E * M), step_off((size_t)E * M);   // rows [off, off + cnt) of the epoch's permuted copy
+    std::vector<int64_t> own_perm;                                       // owned mode: [E][TN] local row ids, compacted per epoch
+    std::vector<int64_t> epoch_rows(E, TN);                              // rows the epoch's gather copies
+    int mb = (int)(TN / M);
+    int64_t mb_global = (int64_t)mb * (ctx->use_comm ? world : 1);
+    if (owned) {
+        const int64_t Ng = (int64_t)r->N * world;
+        mb_global = TN_perm / M;
+        own_perm.assign((size_t)E * TN, 0);
+        mb = 1;
+        for (int e = 0; e < E; ++e) {
+            int64_t n_own = 0;
+            for (int k = 0; k < M; ++k) {
+                step_off[(size_t)e * M + k] = (int)n_own;
+                for (int64_t i = 0; i < mb_global; ++i) {
+                    const int64_t g = perms[(size_t)e * TN_perm + (size_t)k * mb_global + i];
+                    const int64_t t = g / Ng, c = g - t * Ng, owner = c / r->N;
+                    if (owner == ctx->rank) own_perm[(size_t)e * TN + n_own++] = t * r->N + (c - owner * r->N);
+                }
+                const int cnt = (int)n_own - step_off[(size_t)e * M + k];
+                step_cnt[(size_t)e * M + k] = cnt;
+                if (cnt > mb) mb = cnt;
+            }
+            epoch_rows[e] = n_own;
+        }
+    } else {
+        for (int e = 0; e < E; ++e)
+            for (int k = 0; k < M; ++k) { step_cnt[(size_t)e * M + k] = mb; step_off[(size_t)e * M + k] = k * mb; }
+    }
 
     // advantages (global mean / unbiased std)
     float* adv = r->d_field[SG_F_ADVANTAGES];
@@ -234,8 +276,11 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         SG_CHECK(hipMalloc((void**)&a->d_perms, sizeof(int64_t) * (size_t)E * TN));
         a->perms_cap = (int64_t)E * TN;
     }
-    a->last_perm_count = (int64_t)E * TN;
-    if (perms) {
+    a->last_perm_count = owned ? 0 : (int64_t)E * TN;   // owned mode: the device holds this rank's share only
+    if (owned) {
+        SG_CHECK(hipMemcpyAsync(a->d_perms, own_perm.data(), sizeof(int64_t) * (size_t)E * TN, hipMemcpyHostToDevice, ctx->stream));
+        SG_CHECK(hipStreamSynchronize(ctx->stream));   // own_perm goes out of scope with this call
+    } else if (perms) {
         SG_CHECK(hipMemcpyAsync(a->d_perms, perms, sizeof(int64_t) * (size_t)E * TN, hipMemcpyHostToDevice, ctx->stream));
     } else {
         for (int e = 0; e < E; ++e)
@@ -257,7 +302,8 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     const int mbp = G * R;
     const int ldP = stack_ldP(d);
     const int slab_stride = d.total + 8;
-    const int TNp = (int)TN + 64;        // slack rows: the last row tile may read past the last minibatch
+    // slack rows: the last row tile may read past the last minibatch (owned mode: a short step still reads mbp rows)
+    const int TNp = (int)TN + 64 + (owned ? mbp : 0);
 
     // scratch: slabs | epoch copy (X, ACT, SC) | per-trunk row stacks (H1, H2, OUT)
     const size_t slab_f = (size_t)G * slab_stride;
@@ -297,7 +343,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
 
     PpoArgs pa;
     pa.d = d; pa.params = a->policy->d_params;
-    pa.sc_stride = TNp; pa.mb = mb; pa.mbp = mbp; pa.inv_B = 1.0f / (float)((int64_t)mb * world);
+    pa.sc_stride = TNp; pa.mb = mb; pa.mbp = mbp; pa.inv_B = 1.0f / (float)mb_global;
     pa.clip = a->cfg.clip_param; pa.vcoef = a->cfg.value_loss_coef; pa.ecoef = a->cfg.entropy_coef;
     pa.use_clipped = a->cfg.use_clipped_value_loss;
     pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
@@ -322,9 +368,11 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
         hipLaunchKernelGGL(k_opt_prepare_first, dim3(1), dim3(1), 0, ctx->stream, st);
         for (int e = 0; e < E; ++e) {
             ga.perm = a->d_perms + (size_t)e * TN;
-            hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
+            ga.TN = epoch_rows[e];
+            if (ga.TN) hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((ga.TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
             for (int k = 0; k < M; ++k) {
-                const size_t rb = (size_t)k * mb;
+                const size_t rb = (size_t)step_off[(size_t)e * M + k];
+                pa.mb = step_cnt[(size_t)e * M + k];
                 pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
                 if (!fused) {
                     pa.wbuf_floats = wb_f;
@@ -352,8 +400,8 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, uin
     // RCCL build refuses falls back to direct launches.
     const char* genv = getenv("SG_PPO_GRAPH");
     const char* gcenv = getenv("SG_PPO_GRAPH_COMM");
-    const bool comm_ok = !ctx->use_comm || (!a->graph_refused && !(gcenv && !strcmp(gcenv, "0")));
-    bool use_graph = comm_ok && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
+    const bool comm_ok = !ctx->use_comm || (!a->graph_refused && sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0")));
+    bool use_graph = comm_ok && !owned && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
     if (use_graph) {
         uint32_t fbits[6];
         const float fv[6] = {a->cfg.clip_param, a->cfg.value_loss_coef, a->cfg.entropy_coef, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B};

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Kernel trace + FETCH_SIZE / WRITE_SIZE PMC passes (separate runs) + the bench line for ONE workload of bench.py.
+# Usage (repo root, GPU box):  bash tools/profile_workload.sh <tag> <northstar|hopper|laikago|refine>
+# Writes gpurun_out/<tag>_<workload>_{kernel_trace,pmc_fetch_size,pmc_write_size}.txt and <tag>_<workload>_bench.json;
+# copy what should be judged into profiles/ and regenerate profiles/traffic.json with tools/make_traffic.py.
+set -u
+tag=${1:-rXX}
+wl=${2:-northstar}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+run_prof() {  # name, rocprofv3 args...
+    local name=$1; shift
+    rm -rf /tmp/prof_${wl}_$name
+    timeout 600 rocprofv3 "$@" -d /tmp/prof_${wl}_$name -o $name --output-format rocpd -- python $root/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /tmp/prof_${wl}_$name.out 2> /tmp/prof_${wl}_$name.err
+    find /tmp/prof_${wl}_$name -name "*.db" | head -1
+}
+db=$(run_prof trace --kernel-trace)
+python $root/tools/rocpd_stats.py $db > $out/${tag}_${wl}_kernel_trace.txt
+db=$(run_prof fetch --pmc FETCH_SIZE --kernel-trace)
+python $root/tools/rocpd_pmc.py $db > $out/${tag}_${wl}_pmc_fetch_size.txt
+db=$(run_prof write --pmc WRITE_SIZE --kernel-trace)
+python $root/tools/rocpd_pmc.py $db > $out/${tag}_${wl}_pmc_write_size.txt
+cd $root
+timeout 900 python bench.py --workload $wl --cpu-seconds 8 > $out/${tag}_${wl}_bench.json 2> $out/${tag}_${wl}_bench.err
+head -12 $out/${tag}_${wl}_kernel_trace.txt
+head -6 $out/${tag}_${wl}_pmc_fetch_size.txt
+head -6 $out/${tag}_${wl}_pmc_write_size.txt
+cut -c1-200 $out/${tag}_${wl}_bench.json
