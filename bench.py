@@ -14,13 +14,19 @@ region starts; nothing is skipped inside it.
 2048 envs -> 256 per GPU, obs 111, 8 minibatches, clip 0.1, lr 1.5e-4 with linear decay): no discriminator, one step =
 get_value + GAE + PPO.update + after_update.
 
-N > 1: launched by torch.distributed.run, one process per GPU; control plane (barrier, id
-broadcast, max-over-ranks) on gloo, data plane (gradient all-reduce) on RCCL inside the library.
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU; control plane (barrier, id broadcast, max-over-ranks) on gloo, data plane (gradient
+all-reduce) on RCCL inside the library.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment),
+or plainly as `python bench.py --gpus N`: it then starts the N ranks itself (the same torch.distributed.run command),
+forwards rank 0's line and returns non-zero if any rank failed.  Prints ONE JSON line on rank 0.
+
+`--loopback` (self-test of the N > 1 path on a box with fewer than N GPUs): the ranks share the visible device(s) and use
+the library's shared-memory loopback communicator instead of RCCL; the line says so and is not a scaling measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -192,6 +198,29 @@ def cpu_baseline(w, expert, budget_s):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: run the N ranks under torch.distributed.run (what the
+    driver's own command line does), hand rank 0's JSON line through, fail if any rank fails or no line appears."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines[-1:]:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        raise SystemExit(proc.returncode)
+    if not lines:
+        raise SystemExit("bench.py: the ranks exited cleanly but rank 0 printed no result line")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +230,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
+    ap.add_argument("--loopback", action="store_true",
+                    help="self-test: the N ranks share the visible device(s) and use the shared-memory loopback communicator")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     # Exactly ONE line on stdout: RCCL (and anything else underneath) writes banners to the C-level stdout, which would land
     # before or after the JSON line depending on buffering.  Everything written to fd 1 from here on goes to stderr; the
@@ -222,14 +255,27 @@ def main():
 
     import simgan_amd as sg
     from simgan_amd import _lib
-    ctx = _lib.Context.default()   # device = LOCAL_RANK
+    if args.loopback:   # ranks share the visible device(s): LOCAL_RANK modulo their number (SG_LOOPBACK_DEVICES, default 1)
+        ctx = _lib.Context(pg.local_rank % max(1, int(os.environ.get("SG_LOOPBACK_DEVICES", "1")))).make_default()
+    else:
+        ctx = _lib.Context.default()   # device = LOCAL_RANK
     lib = ctx.lib
-    pg.init_device_comm(ctx, _lib.comm_unique_id)
+    pg.init_device_comm(ctx, _lib.comm_loopback_id if args.loopback else _lib.comm_unique_id)
     if world == 1 and os.environ.get("SG_COMM_ALWAYS") == "1":   # one-rank communicator: the collectives run as identities
         ctx.comm_init(_lib.comm_unique_id(), 0, 1)
 
+    dbg = (lambda tag: sys.stderr.write(f"[bench dbg] rank {rank} {tag}: comm {ctx.comm_kind()} {ctx.comm_info()}\n")) if os.environ.get("SG_BENCH_DEBUG") else (lambda tag: None)
+    dbg("after comm init")
+    if os.environ.get("SG_BENCH_FAIL_RANK") == str(rank):   # test hook: a rank that dies (tests/test_gpu_world.py)
+        raise SystemExit(f"rank {rank}: SG_BENCH_FAIL_RANK set")
     w = WORKLOADS[args.workload]
     pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, seed=0)
+    if disc is not None:   # the discriminator's draw streams are global: every rank must hold the same seed
+        seeds = pg.gather_object(int(disc.seed))
+        if len(set(seeds)) != 1:
+            raise SystemExit(f"discriminator seeds differ across ranks ({seeds}): expert permutation / alpha would diverge")
+    dbg("after build_problem")
+    assert pol.ctx is ctx and ro.ctx is ctx and agent.ctx is ctx, "the bench objects must live on the context that holds the communicator"
     _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
 
     def barrier():
@@ -308,8 +354,11 @@ def main():
             "per_rank_ms_per_step": [round(1e3 * x / args.steps, 3) for x in per_rank],
         }
         if world > 1 or force_alt:
-            out["comm"] = {"backend": "RCCL (dlopen) on the library stream, captured into the update's hipGraphs",
-                           "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
+            kind = ctx.comm_kind()
+            out["comm"] = {"backend": ("RCCL (dlopen) on the library stream, captured into the update's hipGraphs" if kind == "rccl" else
+                                       "LOOPBACK self-test (shared-memory transport, ranks share a device): exercises the N > 1 code "
+                                       "path, NOT a scaling measurement"),
+                           "kind": kind, "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
                            "disc_mode": "sharded" if ctx.disc_sharded else "replicated"}
     else:
         out = None

@@ -183,6 +183,11 @@ class Context:
                 _CTX[dev] = Context(0)
         return _CTX[dev]
 
+    def make_default(self):
+        """Make this context the one `Context.default()` returns in this process (objects built without ctx= land on it)."""
+        _CTX[int(os.environ.get("LOCAL_RANK", "0"))] = self
+        return self
+
     def synchronize(self):
         check(self.lib.sg_ctx_synchronize(self.h))
 

@@ -36,7 +36,7 @@ _ALLOWED = {
     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
     ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
     ("torch.nn.parameter", "Parameter"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
-    ("torch.serialization", "_get_layout"), ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"),
+    ("torch.serialization", "_get_layout"), ("torch.storage", "UntypedStorage"),
     ("torch.storage", "TypedStorage"),
     ("torch.nn.modules.linear", "Linear"), ("torch.nn.modules.activation", "Tanh"),
     ("torch.nn.modules.container", "Sequential"), ("torch.optim.adam", "Adam"),

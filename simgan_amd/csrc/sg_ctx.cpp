@@ -147,7 +147,6 @@ SgEv sg_prof_events(sg_ctx* ctx, int which) {
 
 static void prof_drain(sg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
-    sg_comm_destroy(ctx);
     for (auto& s : ctx->prof) {
         for (auto& p : s.pending) {
             float ms = 0.f;

@@ -57,6 +57,14 @@ class ProcessGroup(object):
         self.dist.all_gather_object(box, float(value))
         return box
 
+    def gather_object(self, obj):
+        """Any picklable object per rank -> the list of all ranks' objects (on every rank)."""
+        if self.dist is None:
+            return [obj]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, obj)
+        return box
+
     def init_device_comm(self, ctx, make_unique_id):
         """Create the RCCL communicator on `ctx`: rank 0 draws the id, everyone joins."""
         if self.world == 1:

@@ -9,6 +9,9 @@ from . import _lib
 from .utils import derive_seed, orthogonal, to_host_tensor
 
 
+MATERIALISE_CTX = None   # context for policies that build their device twin lazily (bare torch.load); None = Context.default()
+
+
 class _PolicyBase(object):
     KIND = None
 
@@ -24,7 +27,7 @@ class _PolicyBase(object):
         n = C.c_int64(0)
         _lib.check(self.lib.sg_policy_num_params(self.h, C.byref(n)))
         self.num_params = n.value
-        self.seed = derive_seed(0, 0x5EED)   # action-noise stream; re-derived from the constructor seed below
+        self.seed = derive_seed(0, 0x5EED, per_instance=True)   # action-noise stream; re-derived from the constructor seed below
         self._act_calls = 0
 
     def __del__(self):
@@ -47,10 +50,20 @@ class _PolicyBase(object):
     def _materialise(self):
         from .checkpoint import policy_from_module_state
         st = self.__dict__.pop("_pending")
-        dims, sd = policy_from_module_state(type(self).__name__, st)
-        self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], None)
-        self.seed = derive_seed(0, 0x5EED)
-        self.load_state_dict(sd)
+        try:
+            dims, sd = policy_from_module_state(type(self).__name__, st)
+            # the context an unpickled policy lands on: `simgan_amd.model.MATERIALISE_CTX` when the loader set one
+            # (checkpoint.load_policy(ctx=...)), the process default otherwise
+            self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], MATERIALISE_CTX)
+            self.seed = derive_seed(0, 0x5EED, per_instance=True)
+            self.load_state_dict(sd)
+        except BaseException:
+            # keep the pickled state: the next attribute access retries (and raises the real cause again) instead of a
+            # bare AttributeError with the state lost
+            for k in ("h", "ctx", "lib"):
+                self.__dict__.pop(k, None)
+            self.__dict__["_pending"] = st
+            raise
 
     # ---- nn.Module-ish surface the reference mains touch
     @property
@@ -115,7 +128,7 @@ class _PolicyBase(object):
             self.__dict__["_pending"] = st
             return
         self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None)
-        self.seed = derive_seed(0, 0x5EED)
+        self.seed = derive_seed(0, 0x5EED, per_instance=True)
         self.set_flat_params(st["flat"])
 
     # ---- the three calls on the hot path
@@ -170,7 +183,7 @@ class Policy(_PolicyBase):
             raise NotImplementedError("only Box action spaces (a2c/model.py:55-57)")
         hidden = base_kwargs.get("hidden_size", 64)
         self._create(obs_shape[0], action_space.shape[0], hidden, 1, ctx)
-        self.seed = derive_seed(seed, 0x5EED)
+        self.seed = derive_seed(seed, 0x5EED, per_instance=True)
         self._init_params(np.random.default_rng(seed))
 
     def param_shapes(self):

@@ -18,7 +18,7 @@ class SplitPolicy(_PolicyBase):
         num_outputs = action_space.shape[0]
         assert num_outputs == (4 + 3) * num_feet  # contact 4, act 3   (a2c/model_split.py:205)
         self._create(obs_shape[0], num_outputs, hidden, num_feet, ctx)
-        self.seed = derive_seed(seed, 0x5EED)
+        self.seed = derive_seed(seed, 0x5EED, per_instance=True)
         self._init_params(np.random.default_rng(seed))
 
     def param_shapes(self):

@@ -149,31 +149,45 @@ class RolloutStorage(object):
                                                        1 if use_proper_time_limits else 0))
         self._pull([_lib.F_RETURNS, _lib.F_VALUE_PREDS])
 
-    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
-        """a2c/storage.py:144-192 -- host-side generator kept for API completeness (the device
-        PPO / discriminator updates gather rows themselves and do not use it)."""
-        num_steps, num_processes = self.rewards.shape[0:2]
-        batch_size = num_processes * num_steps
-        if mini_batch_size is None:
-            assert batch_size >= num_mini_batch, (
-                "PPO requires the number of processes ({}) "
-                "* number of steps ({}) = {} "
-                "to be greater than or equal to the number of PPO mini batches ({})."
-                "".format(num_processes, num_steps, num_processes * num_steps, num_mini_batch))
-            mini_batch_size = batch_size // num_mini_batch
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, perm=None):
+        """a2c/storage.py:144-192 -- host-side generator kept for API completeness (the device PPO / discriminator
+        updates gather rows themselves and do not use it).  `perm` injects the sampler's permutation of the T*N row ids
+        (the reference draws torch.randperm through SubsetRandomSampler, a2c/storage.py:159-162); default: numpy's
+        global generator."""
+        return feed_forward_batches(self, advantages, num_mini_batch, mini_batch_size, perm)
+
+
+def feed_forward_batches(ro, advantages, num_mini_batch=None, mini_batch_size=None, perm=None):
+    """The generator body on any object carrying the rollout's host buffers (needs no device): yields the reference's
+    10-tuple (obs, hxs, actions, value_preds, returns, masks, old_logp, adv | None, obs_feat, next_obs_feat) per minibatch,
+    rows in flattened (t, n) order t*N+n, "cur" fields from slots [:-1], next_obs_feat from obs_feat[1:], the ragged tail
+    dropped (BatchSampler(drop_last=True))."""
+    num_steps, num_processes = ro.rewards.shape[0:2]
+    batch_size = num_processes * num_steps
+    if mini_batch_size is None:
+        assert batch_size >= num_mini_batch, (
+            "PPO requires the number of processes ({}) "
+            "* number of steps ({}) = {} "
+            "to be greater than or equal to the number of PPO mini batches ({})."
+            "".format(num_processes, num_steps, num_processes * num_steps, num_mini_batch))
+        mini_batch_size = batch_size // num_mini_batch
+    if perm is None:
         perm = np.random.permutation(batch_size)
+    else:
+        perm = _lib.as_i64(perm).reshape(-1)
+        assert perm.size == batch_size and np.array_equal(np.sort(perm), np.arange(batch_size)), "perm must be a permutation of the T*N row ids"
 
-        def flat(t, sl):
-            a = t.numpy() if hasattr(t, "numpy") else t
-            a = a[sl]
-            return a.reshape(-1, a.shape[-1])
+    def flat(t, sl):
+        a = t.numpy() if hasattr(t, "numpy") else t
+        a = a[sl]
+        return a.reshape(-1, a.shape[-1])
 
-        cur, nxt, al = slice(None, -1), slice(1, None), slice(None)
-        for k in range(batch_size // mini_batch_size):  # drop_last
-            idx = perm[k * mini_batch_size:(k + 1) * mini_batch_size]
-            g = lambda t, sl: to_host_tensor(np.ascontiguousarray(flat(t, sl)[idx]))  # noqa: E731
-            adv = None if advantages is None else to_host_tensor(
-                np.ascontiguousarray(_lib.as_f32(advantages).reshape(-1, 1)[idx]))
-            yield (g(self.obs, cur), g(self.recurrent_hidden_states, cur), g(self.actions, al),
-                   g(self.value_preds, cur), g(self.returns, cur), g(self.masks, cur),
-                   g(self.action_log_probs, al), adv, g(self.obs_feat, cur), g(self.obs_feat, nxt))
+    cur, nxt, al = slice(None, -1), slice(1, None), slice(None)
+    for k in range(batch_size // mini_batch_size):  # drop_last
+        idx = perm[k * mini_batch_size:(k + 1) * mini_batch_size]
+        g = lambda t, sl: to_host_tensor(np.ascontiguousarray(flat(t, sl)[idx]))  # noqa: E731
+        adv = None if advantages is None else to_host_tensor(
+            np.ascontiguousarray(_lib.as_f32(advantages).reshape(-1, 1)[idx]))
+        yield (g(ro.obs, cur), g(ro.recurrent_hidden_states, cur), g(ro.actions, al),
+               g(ro.value_preds, cur), g(ro.returns, cur), g(ro.masks, cur),
+               g(ro.action_log_probs, al), adv, g(ro.obs_feat, cur), g(ro.obs_feat, nxt))

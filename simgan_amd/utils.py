@@ -11,12 +11,17 @@ except Exception:  # pragma: no cover
 _INSTANCES = [0]
 
 
-def derive_seed(seed, salt):
-    """RNG seed of one stochastic object: a splitmix64 hash of (constructor seed, salt, per-process instance
-    counter), so two policies / agents / discriminators never share a noise stream and a different constructor
-    seed gives different draws.  Reproducible for a fixed construction order; override with `obj.seed = x`."""
-    _INSTANCES[0] += 1
-    x = (int(seed) * 0x9E3779B97F4A7C15 + int(salt) * 0xD6E8FEB86659FD93 + _INSTANCES[0] * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+def derive_seed(seed, salt, per_instance=False):
+    """RNG seed of one stochastic object: a splitmix64 hash of (constructor seed, salt).  The streams that must agree
+    across the ranks of a data-parallel run -- the discriminator's DataLoader shuffle and mixup alpha are GLOBAL draws,
+    csrc/sg_disc.hip -- depend on nothing else, so they are the same on every rank whatever else a rank has built.
+    `per_instance=True` (policies: action noise) also mixes in a per-process instance counter, so two policies built
+    with the same constructor seed do not share a noise stream.  Override with `obj.seed = x`."""
+    inst = 0
+    if per_instance:
+        _INSTANCES[0] += 1
+        inst = _INSTANCES[0]
+    x = (int(seed) * 0x9E3779B97F4A7C15 + int(salt) * 0xD6E8FEB86659FD93 + inst * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
     x ^= x >> 30
     x = (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
     x ^= x >> 27

@@ -1,27 +1,34 @@
-"""GPU: the EXACT path bench.py times, end to end against the oracle.
+"""GPU: the EXACT path bench.py times, end to end against the oracle, for every workload bench.py knows.
 
-bench.py's timed region is `GailDynLearner.update()` on a device-resident rollout with the library's own random
-draws and hipGraph replay: 5 x 512 discriminator steps, the alive-bonus offset from the device done count, the
-fused relabel, GAE with the value of obs[T] computed on device, 160 PPO steps, the device after_update.  Here the
-same object graph is built by bench.build_problem, two consecutive updates run exactly as bench.py runs them, the
-draws every phase consumed are exported (sg_disc_last_draws / sg_ppo_last_perms) and the identical two updates are
-replayed through oracle/sg_oracle.c (about a minute of one CPU core).
+bench.py's timed region is `GailDynLearner.update()` (northstar / hopper / laikago) or `PpoLearner.update()` (refine) on a
+device-resident rollout with the library's own random draws and hipGraph replay: 5 x n_d discriminator steps, the alive-bonus
+offset from the device done count, the fused relabel, GAE with the value of obs[T] computed on device, E x M PPO steps, the
+device after_update.  Here the same object graph is built by bench.build_problem, two consecutive updates run exactly as
+bench.py runs them, the draws every phase consumed are exported (sg_disc_last_draws / sg_ppo_last_perms) and the identical
+two updates are replayed through oracle/sg_oracle.c.
 
-Tolerances.  Single kernels agree with the oracle to ~1e-6.  What north_star pins at 1e-4 -- the discriminator and PPO
-losses, the relabelled rewards and the GAE returns -- is checked at 1e-4 relative (plus a small absolute floor where the
-quantity passes through zero).  The discriminator trajectory (2,560 Adam steps per update) is smooth: two float32
-evaluations that differ only in summation order stay within ~1e-7 of each other, and the weights are compared
-elementwise.  The POLICY trajectory is not: 160 clipped-surrogate Adam steps amplify a one-ulp difference in the rewards to
-~3e-4 absolute on individual weights (~1 % of the update's L2 length) -- measured with the oracle against itself,
-tools/trajectory_sensitivity.py -- because rows on a clip / min / max boundary flip branch and Adam turns a flipped
-near-zero gradient into a full lr-sized step.  No two float32 implementations (the reference under two BLAS builds
-included) can agree elementwise beyond that (SplitPolicy, with its state-dependent log-std: 4.3 % / 5.0e-4 under a 1e-5
-perturbation, `tools/trajectory_sensitivity.py hopper`), so the post-update policy is checked as a trajectory: relative L2
-distance <= 10 % of the update's length (about twice the measured float32 floor) and worst entry <= 2e-3, with the measured
-values printed; the oracle's policy state is then re-seeded from the device so the second update is compared from an
-identical start.  The same holds for the action loss, a near-zero mean of +-advantage x ratio terms (-0.003 .. -0.05): it is
-compared at 1e-4 relative plus 5e-5 absolute (self-sensitivity 1e-5 absolute)."""
+What is compared, and how tightly (GATES below; every measured deviation is also written to the JSON file named by
+SG_PARITY_RECORD -- the committed record of a run is profiles/r03_parity.json):
+
+* Everything north_star pins at 1e-4 -- discriminator losses, relabelled rewards, GAE returns, Discriminator.returns, PPO
+  losses -- at 1e-4 RELATIVE plus an absolute floor for the quantities that pass through zero (rewards are clipped to
+  [-10, 10] and centred on 0; the action loss is a near-zero mean of +-advantage x ratio terms).  The floors are about
+  twice the deviation measured on MI355X, per workload.
+* The discriminator trajectory (2,560 Adam steps per update) is smooth: weights are compared elementwise.
+* The POLICY trajectory is chaotic in float32: E x M clipped-surrogate Adam steps amplify a one-ulp difference in the rewards
+  to ~3e-4 absolute on individual weights (~1 % of the update's L2 length at the north-star shape), measured with the oracle
+  against ITSELF (tools/trajectory_sensitivity.py -> profiles/r03_parity_floor.json), because rows on a clip / min / max
+  boundary flip branch and Adam turns a flipped near-zero gradient into a full lr-sized step.  No two float32
+  implementations can agree elementwise beyond that, so the post-update policy is gated as a trajectory -- relative L2
+  distance of the update and worst entry, at about twice that workload's own float32 floor.
+* Two oracle tracks for the second update.  CONTINUOUS: the oracle carries its own policy and Adam state over from the
+  first update (nothing is re-seeded from the device) -- the honest end-to-end comparison, gated at twice the one-update
+  floor since two updates' drift compounds.  RE-SEEDED: the oracle restarts the second update from the device's weights and
+  moments, which isolates that update and is gated like the first.
+"""
 import ctypes as C
+import json
+import os
 import time
 
 import numpy as np
@@ -31,98 +38,179 @@ from helpers import assert_close
 
 pytestmark = pytest.mark.gpu
 
+# Per workload: (policy rel-L2 gate, policy worst-entry gate) for ONE update from an identical start, then absolute floors
+# for rewards / returns / Discriminator.returns (all at rtol 1e-4) and for the PPO losses.  Float32 floors of the policy
+# trajectory (profiles/r03_parity_floor.json, perturbation 1e-6 / 1e-5): northstar 1.2e-2 / 2.8e-4, hopper 4.3e-2 / 5.0e-4,
+# laikago and refine: see that file.  Measured MI355X deviations: profiles/r03_parity.json.
+GATES = {
+    "northstar": dict(pi_l2=3e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
+    "hopper": dict(pi_l2=9e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
+    "laikago": dict(pi_l2=9e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
+    "refine": dict(pi_l2=3e-2, pi_worst=1e-3, rew_atol=0.0, ret_atol=2e-5, cont_ret_atol=5e-3, loss_atol=5e-5),
+}
+
 
 def _flat2(a):
     return a.numpy()[..., 0] if hasattr(a, "numpy") else np.asarray(a)[..., 0]
 
 
-@pytest.mark.parametrize("workload", ["northstar", "hopper"])
+def _dev(a, b):
+    """(max abs error, max error in units of 1e-4 * |b|-relative tolerance without any floor, i.e. worst relative error)"""
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    e = np.abs(a - b)
+    return dict(max_abs=float(e.max()), max_rel=float(np.max(e / (np.abs(b) + 1e-30))), rel_of_max=float(e.max() / (np.abs(b).max() + 1e-30)))
+
+
+def _record(workload, rec):
+    path = os.environ.get("SG_PARITY_RECORD")
+    if not path:
+        return
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        doc = {"what": "deviation of the HIP path from the oracle on the exact path bench.py times (two consecutive updates, "
+                       "library RNG, graphs on); written by tests/test_gpu_benchpath.py under SG_PARITY_RECORD", "workloads": {}}
+    doc["workloads"][workload] = rec
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
+@pytest.mark.parametrize("workload", ["northstar", "hopper", "laikago", "refine"])
 def test_bench_path_two_updates_vs_oracle(workload):
-    """northstar: BASELINE.json's synthetic measurement shape (Policy h64, 2,560 + 160 steps per update); hopper:
-    configs[1] as shipped (HopperCombinedEnv-v1 shapes, SplitPolicy h100 with state-dependent log-std, 256 envs: 1,280 + 160
-    steps per update)."""
+    """northstar: BASELINE.json's synthetic measurement shape (Policy h64, 2,560 + 160 steps per update); hopper: configs[1]
+    as shipped (SplitPolicy h100, 256 envs: 1,280 + 160 steps); laikago: configs[2] real shapes (SplitPolicy h100, 4 feet, obs
+    64 / act 28, 512 envs: 2,560 + 160 steps); refine: configs[4] per-rank shape through PpoLearner (a2c/main.py caller: obs
+    111, 8 minibatches, clip 0.1, lr 1.5e-4 linearly decayed, no discriminator: 80 steps)."""
     import bench
     import simgan_amd as sg
     from oracle import oracle as orc
     from simgan_amd import _lib
 
     w = bench.WORKLOADS[workload]
+    gate = GATES[workload]
     T, N, O, A, F, H, Hd, B = w["T"], w["N"], w["O"], w["A"], w["F"], w["H"], w["Hd"], w["B"]
-    n_d_expected = min(w["Ne"] // B, T * N // B)
+    has_d = bool(w["E_d"])
+    n_d_expected = min(w["Ne"] // B, T * N // B) if has_d else 0
+    lr0 = w.get("lr", 3e-4)
     pol, disc, agent, ro, loader, expert, learner = bench.build_problem(sg, w, seed=0)
     lib = _lib.load()
     _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
     assert ro.device_resident
 
-    # record the draws of every discriminator epoch without touching what runs on the device
-    draws = []
-    real_update = disc.update_gail_dyn
+    draws = []   # the draws of every discriminator epoch, recorded without touching what runs on the device
+    if has_d:
+        real_update = disc.update_gail_dyn
 
-    def recording_update(*a, **k):
-        out = real_update(*a, **k)
-        draws.append(disc.last_draws())
-        return out
+        def recording_update(*a, **k):
+            out = real_update(*a, **k)
+            draws.append(disc.last_draws())
+            return out
 
-    disc.update_gail_dyn = recording_update
+        disc.update_gail_dyn = recording_update
 
     d = orc.dims(orc.KIND_MLP if w["kind"] == "mlp" else orc.KIND_SPLIT, O, A, H, w["feet"])
-    pi, dp = pol.get_flat_params(), disc.get_flat_params()
-    pi_adam, d_adam = orc.AdamState(pi.size), orc.AdamState(dp.size)
-    cfg = orc.ppo_cfg(w["clip"], w["E_p"], w["M"], 0.5, 0.0, 3e-4, 1e-5, 0.5, True)
+    pi = pol.get_flat_params()                       # CONTINUOUS oracle track: never re-seeded from the device
+    pi_adam = orc.AdamState(pi.size)
+    dp = d_adam = None
+    if has_d:
+        dp = disc.get_flat_params()
+        d_adam = orc.AdamState(dp.size)
     d_ret, rms = None, [0.0, 1.0, 1e-4]
     t_orc = 0.0
+    record = {"shape": {k: w[k] for k in ("T", "N", "O", "A", "F", "H", "Hd", "E_p", "M", "E_d", "B", "kind")}, "gates": gate, "updates": []}
     for it in range(2):
-        ro.sync_from_device()                       # the update's input, as it sits in HBM
+        ro.sync_from_device()                        # the update's input, as it sits in HBM
         obs, obs_feat = ro.obs.numpy().copy(), ro.obs_feat.numpy().copy()
         actions, logp = ro.actions.numpy().copy(), _flat2(ro.action_log_probs).copy()
         vp, masks, bad = _flat2(ro.value_preds).copy(), _flat2(ro.masks).copy(), _flat2(ro.bad_masks).copy()
+        rewards_in = _flat2(ro.rewards).copy()
+        p_dev0 = pol.get_flat_params()               # RE-SEEDED oracle track starts every update from the device's state
+        m0, v0, t0_ = agent.get_adam()
         draws.clear()
-        out = learner.update()                      # == the body of bench.py's timed loop
+        out = learner.update()                       # == the body of bench.py's timed loop
         perms = agent.last_perms()
-        assert len(draws) == w["E_d"] and perms.shape == (w["E_p"], T * N)
-        for ep_, pp_, al_ in draws:                 # the library's own draws are what the reference's would be: bijections, U[0,1)
+        assert perms.shape == (w["E_p"], T * N) and len(draws) == w["E_d"]
+        for ep_, pp_, al_ in draws:                  # the library's own draws are what the reference's would be: bijections, U[0,1)
             assert np.array_equal(np.sort(ep_), np.arange(w["Ne"])) and np.array_equal(np.sort(pp_), np.arange(T * N))
             assert al_.size == n_d_expected * B and al_.min() >= 0.0 and al_.max() < 1.0
-        assert len({a_[0][:64].tobytes() for a_ in draws}) == w["E_d"], "every epoch must draw a fresh permutation"
+        if has_d:
+            assert len({a_[0][:64].tobytes() for a_ in draws}) == w["E_d"], "every epoch must draw a fresh permutation"
+        assert len({perms[e][:64].tobytes() for e in range(w["E_p"])}) == w["E_p"]
 
-        # ---- the same update through the oracle (a2c/main_gail_dyn_ppo.py:255-304)
-        pi_start = pi.astype(np.float64).copy()
+        # ---- the same update through the oracle (a2c/main_gail_dyn_ppo.py:255-304 / a2c/main.py:199-257)
         t0 = time.perf_counter()
-        for k, (ep_, pp_, al_) in enumerate(draws):
-            dl, n_d = orc.disc_update(F, Hd, dp, d_adam, expert, obs_feat, B, ep_, pp_, al_)
-            assert n_d == n_d_expected
-        r_sa = orc.alive_bonus(masks, T, N, 500.0)
-        rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, bench.GAMMA, -r_sa, d_ret, rms)
-        nv = orc.policy_forward(d, pi, obs[T])[0][:, 0]
-        ret, vp2 = orc.compute_returns(rewards, vp, masks, bad, nv, 1, bench.GAMMA, bench.LAM, 1)
-        pl = orc.ppo_update(d, pi, pi_adam, cfg, obs, actions, vp2, ret, logp, perms)
+        lr = np.float32(lr0 - lr0 * (it / 1000.0)) if not has_d else np.float32(lr0)   # a2c/utils.py:68-72 (refine: num_updates=1000)
+        cfg = orc.ppo_cfg(w["clip"], w["E_p"], w["M"], 0.5, 0.0, float(lr), 1e-5, 0.5, True)
+        dl = r_sa = None
+        if has_d:
+            for ep_, pp_, al_ in draws:
+                dl, n_d = orc.disc_update(F, Hd, dp, d_adam, expert, obs_feat, B, ep_, pp_, al_)
+                assert n_d == n_d_expected
+            r_sa = orc.alive_bonus(masks, T, N, 500.0)
+            rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, bench.GAMMA, -r_sa, d_ret, rms)
+        else:
+            rewards = rewards_in
+        tracks = {}
+        for name, (p_, m_, v_, t_) in (("continuous", (pi, pi_adam.m, pi_adam.v, pi_adam.t.value)), ("reseeded", (p_dev0, m0, v0, t0_))):
+            if it == 0 and name == "reseeded":
+                tracks[name] = tracks["continuous"]
+                continue
+            p_start = np.array(p_, np.float32, copy=True)
+            ad = orc.AdamState(p_start.size)
+            ad.m[:], ad.v[:] = m_, v_
+            ad.t.value = t_
+            nv = orc.policy_forward(d, p_start, obs[T])[0][:, 0]
+            ret, vp2 = orc.compute_returns(rewards, vp, masks, bad, nv, 1, bench.GAMMA, bench.LAM, 1)
+            p_end = p_start.copy()
+            pl = orc.ppo_update(d, p_end, ad, cfg, obs, actions, vp2, ret, logp, perms)
+            tracks[name] = dict(start=p_start, end=p_end, adam=ad, nv=nv, ret=ret, pl=pl)
+        pi = tracks["continuous"]["end"]
+        pi_adam = tracks["continuous"]["adam"]
         t_orc += time.perf_counter() - t0
 
         # ---- compare
         ro.sync_from_device()
-        tag = f"update {it}: "
-        assert_close(out["r_sa"], r_sa, rtol=1e-9, atol=0, what=tag + "alive-bonus offset (device done count)")
-        assert_close(_flat2(ro.rewards), rewards, rtol=2e-4, atol=2e-4, what=tag + "relabelled rewards")   # through D after 2,560 steps
-        assert_close(learner.ret_rms.get_state(), rms, rtol=1e-4, what=tag + "ret_rms")
-        assert_close(disc.returns.numpy()[:, 0], d_ret, rtol=2e-4, atol=2e-4, what=tag + "Discriminator.returns")
-        assert_close(_flat2(ro.value_preds)[T], nv, what=tag + "value_preds[T] = get_value(obs[T])")
-        assert_close(_flat2(ro.returns)[:T], ret[:T], rtol=2e-4, atol=2e-4, what=tag + "GAE returns")
-        assert_close([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl, what=tag + "D losses of the last epoch")
-        assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], pl, rtol=1e-4, atol=5e-5, what=tag + "PPO losses")
-        # trajectory level: 2,560 (D) / 160 (pi) Adam steps from identical starts.  Steps are lr-sized (1e-3 / 3e-4), so
-        # a parameter that moved ~0.1-1 carries the accumulated fp32 reordering noise of every step: 1e-4 relative on the
-        # weights' own scale + a 2e-4 absolute floor for the entries near zero.
-        p_hip, d_hip = pol.get_flat_params(), disc.get_flat_params()
-        assert_close(d_hip, dp, rtol=1e-4, atol=2e-4, what=tag + "D weights after 2,560 steps")
-        assert np.abs(dp).max() > 0.1 and np.abs(d_hip - dp).max() < 1e-3 * np.abs(dp).max()
-        move = np.linalg.norm(pi.astype(np.float64) - pi_start)
-        rel_l2 = np.linalg.norm(p_hip.astype(np.float64) - pi) / move
-        worst = np.abs(p_hip - pi).max()
-        frac = float(np.mean(np.abs(p_hip - pi) > 5e-5 + 1e-4 * np.abs(pi)))
-        print(f"{tag}policy after 160 steps: rel L2 of the update {rel_l2:.2e}, worst entry {worst:.2e}, "
-              f"{100 * frac:.1f} % of entries beyond 1e-4 rel (float32 self-sensitivity: MLP 1.2e-02 / 2.8e-04 / 17.5 %, split 4.3e-02 / 5.0e-04 / 39 %)")
-        assert rel_l2 <= 1e-1 and worst <= 2e-3, (rel_l2, worst)
-        assert move > 0.2, "the update must move the policy far more than the tolerance"
+        tag = f"{workload} update {it}: "
+        rec = {}
+        if has_d:
+            assert_close(out["r_sa"], r_sa, rtol=1e-9, atol=0, what=tag + "alive-bonus offset (device done count)")
+            rec["rewards"] = _dev(_flat2(ro.rewards), rewards)
+            rec["disc_returns"] = _dev(disc.returns.numpy()[:, 0], d_ret)
+            rec["d_losses"] = _dev([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl)
+            assert_close(_flat2(ro.rewards), rewards, rtol=1e-4, atol=gate["rew_atol"], what=tag + "relabelled rewards")   # through D after 2,560 steps
+            assert_close(learner.ret_rms.get_state(), rms, rtol=1e-4, what=tag + "ret_rms")
+            assert_close(disc.returns.numpy()[:, 0], d_ret, rtol=1e-4, atol=gate["rew_atol"], what=tag + "Discriminator.returns")
+            assert_close([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl, what=tag + "D losses of the last epoch")
+            # trajectory level: 2,560 Adam steps (lr 1e-3) from identical starts: 1e-4 relative on the weights' own scale + a
+            # 2e-4 absolute floor for the entries near zero
+            d_hip = disc.get_flat_params()
+            rec["d_weights"] = _dev(d_hip, dp)
+            assert_close(d_hip, dp, rtol=1e-4, atol=2e-4, what=tag + "D weights after the update's discriminator steps")
+            assert np.abs(dp).max() > 0.1 and np.abs(d_hip - dp).max() < 1e-3 * np.abs(dp).max()
+        p_hip = pol.get_flat_params()
+        losses_hip = [out["value_loss"], out["action_loss"], out["dist_entropy"]]
+        for name, mult in (("reseeded", 1.0), ("continuous", 1.0 if it == 0 else 2.0)):
+            tr = tracks[name]
+            move = np.linalg.norm(tr["end"].astype(np.float64) - tr["start"])
+            rel_l2 = float(np.linalg.norm(p_hip.astype(np.float64) - tr["end"]) / move)
+            worst = float(np.abs(p_hip - tr["end"]).max())
+            frac = float(np.mean(np.abs(p_hip - tr["end"]) > 5e-5 + 1e-4 * np.abs(tr["end"])))
+            rec[name] = dict(policy_rel_l2_of_update=rel_l2, policy_worst_entry=worst, policy_frac_beyond_tol=frac, update_l2=float(move),
+                             value_pred_T=_dev(_flat2(ro.value_preds)[T], tr["nv"]), returns=_dev(_flat2(ro.returns)[:T], tr["ret"][:T]),
+                             ppo_losses=_dev(losses_hip, tr["pl"]), ppo_losses_abs=[abs(a - b) for a, b in zip(losses_hip, tr["pl"])])
+            print(f"{tag}[{name}] policy after {w['E_p'] * w['M']} steps: rel L2 of the update {rel_l2:.2e}, worst entry {worst:.2e}, "
+                  f"{100 * frac:.1f} % of entries beyond 1e-4 rel; returns max abs {rec[name]['returns']['max_abs']:.2e}; "
+                  f"PPO losses abs {['%.1e' % x for x in rec[name]['ppo_losses_abs']]}")
+            strict = it == 0 or name == "reseeded"    # identical start of THIS update; otherwise two updates' drift compounds
+            ret_atol = gate["ret_atol"] if strict else gate["cont_ret_atol"]
+            assert_close(_flat2(ro.value_preds)[T], tr["nv"], rtol=1e-4, atol=1e-5 if strict else gate["cont_ret_atol"],
+                         what=tag + name + " value_preds[T] = get_value(obs[T])")
+            assert_close(_flat2(ro.returns)[:T], tr["ret"][:T], rtol=1e-4, atol=ret_atol, what=tag + name + " GAE returns")
+            assert_close(losses_hip, tr["pl"], rtol=1e-4, atol=mult * gate["loss_atol"], what=tag + name + " PPO losses")
+            assert rel_l2 <= mult * gate["pi_l2"] and worst <= mult * gate["pi_worst"], (tag, name, rel_l2, worst)
+            assert move > 0.1, "the update must move the policy far more than the tolerance"
+        record["updates"].append(rec)
 
         # ---- device after_update / count_dones against numpy on the downloaded buffers
         for name in ("obs", "obs_feat", "masks", "bad_masks"):
@@ -132,10 +220,6 @@ def test_bench_path_two_updates_vs_oracle(workload):
         dones = C.c_double(0)
         _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))
         assert dones.value == float((1.0 - ro.masks.numpy()).sum())
-        # the discriminator side carries the oracle's own state into the next update; the policy side (see the module
-        # docstring) restarts from the device's weights and Adam moments
-        pi = p_hip.copy()
-        m_, v_, t_ = agent.get_adam()
-        pi_adam.m[:], pi_adam.v[:] = m_, v_
-        pi_adam.t.value = t_
+    record["oracle_seconds"] = round(t_orc, 1)
+    _record(workload, record)
     print(f"oracle replay of two updates: {t_orc:.1f} s")

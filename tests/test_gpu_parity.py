@@ -728,11 +728,12 @@ def test_injected_draws_are_validated(sg):
     D = sg.algo.gail.Discriminator(F, 16, None)
     ro = sg.RolloutStorage(T, N, (3,), Box((2,)), 1, F)
     loader = Loader(np.zeros((40, F), np.float32), 8)
-    with pytest.raises(AssertionError, match="expert_perm"):
+    from simgan_amd._lib import SimganHipError   # lengths and index ranges are checked behind the C ABI (include/simgan_hip.h)
+    with pytest.raises(SimganHipError, match="expert_perm holds 39"):
         D.update_gail_dyn(loader, ro, expert_perm=np.arange(39))
-    with pytest.raises(AssertionError, match="out of range"):
+    with pytest.raises(SimganHipError, match=r"policy_perm\[31\] = 32 is outside"):
         D.update_gail_dyn(loader, ro, policy_perm=np.arange(1, 33))
-    with pytest.raises(AssertionError, match="alpha"):
+    with pytest.raises(SimganHipError, match="alpha holds 8"):
         D.update_gail_dyn(loader, ro, alpha=np.zeros(8, np.float32))
     losses = D.update_gail_dyn(loader, ro)
     ep, pp, al = D.last_draws()

@@ -119,6 +119,37 @@ def test_env_pool_shards_cover_the_global_pool():
     assert whole.ret_rms.count == pytest.approx(1e-4 + 12 * 8) and shards[0].ret_rms.count == pytest.approx(1e-4 + 12 * 4)
 
 
+def test_feed_forward_generator_yields_the_reference_tuples():
+    """RolloutStorage.feed_forward_generator against the reference's own output (tests/golden/ffgen.npz, written by
+    tools/gen_golden.py from a2c/storage.py:144-192 with the sampler's permutation recorded): PPO form (num_mini_batch,
+    advantages) and discriminator form (mini_batch_size 8 of 20 rows: two batches, ragged tail dropped, advantages None)."""
+    import types
+    from simgan_amd.storage import feed_forward_batches
+    g = dict(np.load(os.path.join(GOLDEN, "ffgen.npz")))
+    ro = types.SimpleNamespace(obs=g["obs"], obs_feat=g["obs_feat"], actions=g["actions"], rewards=g["rewards"],
+                               value_preds=g["value_preds"], returns=g["returns"], action_log_probs=g["action_log_probs"],
+                               masks=g["masks"], bad_masks=g["bad_masks"], recurrent_hidden_states=g["recurrent_hidden_states"])
+    names = ("obs", "hxs", "actions", "value_preds", "returns", "masks", "old_logp", "adv", "obs_feat", "next_obs_feat")
+    for tag, kw, adv in (("ppo", dict(num_mini_batch=3), g["advantages"]), ("disc", dict(mini_batch_size=8), None)):
+        batches = list(feed_forward_batches(ro, adv, perm=g[f"{tag}_perm"], **kw))
+        assert len(batches) == int(g[f"{tag}_n_batches"])
+        for b, tup in enumerate(batches):
+            assert len(tup) == 10
+            for nm, t in zip(names, tup):
+                key = f"{tag}_b{b}_{nm}"
+                if key in g:
+                    assert np.array_equal(np.asarray(t), g[key]), key
+                else:
+                    assert t is None and nm == "adv"
+    with pytest.raises(AssertionError, match="permutation"):
+        next(feed_forward_batches(ro, None, mini_batch_size=8, perm=np.zeros(20, np.int64)))
+    with pytest.raises(AssertionError, match="PPO requires the number of processes"):
+        next(feed_forward_batches(ro, None, num_mini_batch=21))
+    # default draw: still a permutation, every row at most once
+    rows = np.concatenate([np.asarray(t[3])[:, 0] for t in feed_forward_batches(ro, None, mini_batch_size=4)])
+    assert sorted(rows.tolist()) == sorted(g["value_preds"][:-1].reshape(-1).tolist())
+
+
 # -------------------------------------------------------------------------------------- checkpoint safety
 class _Evil:
     def __reduce__(self):
@@ -157,6 +188,31 @@ def test_checkpoint_reader_refuses_torch_and_os_callables(tmp_path):
         torch.save([obj, None], path)
         with pytest.raises(pickle.UnpicklingError, match="refusing to resolve"):
             ck.read_reference_checkpoint(path)
+
+
+def test_checkpoint_reader_refuses_nested_unrestricted_unpickle(tmp_path):
+    """torch.storage._load_from_bytes is torch.load(BytesIO(b), weights_only=False): an allowlisted name that re-enters an
+    UNRESTRICTED unpickler on bytes taken from the file (round-2 advisor finding, with a working proof of concept).  It is
+    not on the allowlist -- legacy checkpoints rebuild storages through persistent_load and never need it -- so a file
+    that smuggles a payload through it is refused and nothing runs."""
+    import io
+    import torch
+    from simgan_amd import checkpoint as ck
+    os.environ.pop("SG_PWNED", None)
+    inner = io.BytesIO()
+    torch.save(_Evil(), inner)
+
+    class Nested:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    for legacy in (True, False):
+        path = str(tmp_path / f"nested_{int(legacy)}.pt")
+        torch.save([Nested(), None], path, _use_new_zipfile_serialization=not legacy)
+        with pytest.raises(pickle.UnpicklingError, match="refusing to resolve"):
+            ck.read_reference_checkpoint(path)
+        assert "SG_PWNED" not in os.environ
+    assert ("torch.storage", "_load_from_bytes") not in ck._ALLOWED
 
 
 def test_no_fixture_carries_reference_source():

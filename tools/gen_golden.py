@@ -581,6 +581,49 @@ def gen_vecnormalize():
          scaled=np.stack(outs), ret=np.stack(rets), rms=np.array(states, np.float64), gamma=np.float64(0.99))
 
 
+def gen_ffgen():
+    """RolloutStorage.feed_forward_generator (a2c/storage.py:144-192): the 10-tuples the reference yields for PPO
+    (num_mini_batch, with advantages) and for the discriminator (mini_batch_size, advantages None, ragged tail dropped),
+    with the permutation each call drew."""
+    global _REC
+    T, N, O, A, F = 5, 4, 3, 2, 4
+    ro = ns.RolloutStorage(T, N, (O,), ns.Box(shape=(A,)), 1, F)
+    fill_rollout(ro, T, N, O, A, F, 700)
+    ro.returns.copy_(torch.randn(T + 1, N, 1, generator=torch.Generator().manual_seed(701)))
+    adv = torch.randn(T, N, 1, generator=torch.Generator().manual_seed(702))
+    out = dict(rollout_arrays(ro), advantages=adv.numpy().copy())
+    out["recurrent_hidden_states"] = ro.recurrent_hidden_states.numpy().copy()
+    names = ("obs", "hxs", "actions", "value_preds", "returns", "masks", "old_logp", "adv", "obs_feat", "next_obs_feat")
+    for tag, kw, a in (("ppo", dict(num_mini_batch=3), adv), ("disc", dict(mini_batch_size=8), None)):
+        torch.manual_seed(710)
+        _REC = []
+        batches = list(ro.feed_forward_generator(a, **kw))
+        out[f"{tag}_perm"] = np.concatenate([r for k, r in _REC if k == "randperm"]).astype(np.int64)
+        out[f"{tag}_n_batches"] = np.int64(len(batches))
+        for b, tup in enumerate(batches):
+            for nm, t in zip(names, tup):
+                if t is not None:
+                    out[f"{tag}_b{b}_{nm}"] = t.numpy().copy()
+    save("ffgen", meta=meta(T=T, N=N, O=O, A=A, F=F, num_mini_batch=3, mini_batch_size=8), **out)
+
+
+def gen_predict_reward():
+    """Discriminator.predict_reward(state, action, gamma, masks, offset) (a2c/algo/gail.py:195-199), two consecutive calls
+    (the second continues self.returns)."""
+    torch.manual_seed(720)
+    S, Ad, Hd, n = 6, 3, 16, 9
+    D = ns.Discriminator(S + Ad, Hd, "cpu")
+    g = torch.Generator().manual_seed(721)
+    out = dict(params=flat_params(D.trunk))
+    for c in range(2):
+        st, ac = torch.randn(n, S, generator=g), torch.randn(n, Ad, generator=g)
+        mk = (torch.rand(n, 1, generator=g) > 0.3).float()
+        rew, ret = D.predict_reward(st, ac, 0.97, mk, offset=0.25 * c)
+        out.update({f"state{c}": st.numpy(), f"action{c}": ac.numpy(), f"masks{c}": mk.numpy(), f"reward{c}": rew.numpy().copy(),
+                    f"returns{c}": ret.numpy().copy()})
+    save("predict_reward", meta=meta(S=S, A=Ad, Hd=Hd, n=n, gamma=0.97), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: python tools/gen_golden.py refine vecnormalize checkpoints
         for what in sys.argv[1:]:
@@ -591,6 +634,9 @@ if __name__ == "__main__":
                 gen_vecnormalize()
             elif what == "checkpoints":
                 gen_checkpoints()
+            elif what == "closures":
+                gen_ffgen()
+                gen_predict_reward()
             else:
                 raise SystemExit(f"unknown fixture group {what}")
         sys.exit(0)
@@ -620,3 +666,5 @@ if __name__ == "__main__":
     gen_iteration("iter_split", "split", 14, 7, 100, 1, F=25, Hd=100, T=8, N=16, B=32, Ne=100, E=2, M=2, Ed=2, iters=2, seed=510)
     gen_refine("iter_refine", O=111, A=12, H=64, T=8, N=16, E=2, M=8, clip=0.1, lr=1.5e-4, num_updates=4, iters=2, logstd=-1.3, seed=600)
     gen_vecnormalize()
+    gen_ffgen()
+    gen_predict_reward()
