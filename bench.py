@@ -90,8 +90,22 @@ def algorithmic_work(w, world, disc_sharded=False):
     flops = w["E_d"] * n_d * d_step_flops + w["E_p"] * w["M"] * ppo_step_flops + relabel_flops
     bytes_ = (w["E_d"] * n_d * 2 * B_rank * F * 4 + (TN * (F + 2) * 4 if w["E_d"] else 0) + TN * 20 + TN * 12 +
               w["E_p"] * w["M"] * mb * (O + A + 4) * 4)
+    # per-launch algorithmic work of every profiled kernel: (kernel name, bound, FLOPs, compulsory HBM bytes)
+    P_pi = (2 * (O * H + H + H * H + H) + H + 1 + H * A + A + A) if w["kind"] == "mlp" else \
+           (3 * (O * H + H + H * H + H) + H + 1 + 2 * (H * 4 * w["feet"] + 4 * w["feet"]) + 2 * (H * 3 * w["feet"] + 3 * w["feet"]))
+    fused = w["kind"] == "mlp"    # Policy: k_ppo_bwd recomputes the forward, no k_ppo_fwd launch
+    fwd_flops = mb * 2 * fwd
+    kernels = {
+        "disc_chain": ("k_disc_chain4", "mfma", d_chain_flops, 2 * B_rank * F * 4),
+        "disc_wgrad": ("k_disc_wgrad", "mfma", d_wgrad_flops, 0),
+        "ppo_fwd": ("k_ppo_fwd", "mfma", 0 if fused else fwd_flops, 0 if fused else mb * O * 4),
+        "ppo_bwd": ("k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused else fwd_flops), mb * (O + A + 4) * 4),
+        "ppo_reduce": ("k_ppo_reduce", "hbm", 0, P_pi * 4),          # the gradient vector; the slabs it sums are an implementation artefact
+        "ppo_adam": ("k_ppo_adam", "hbm", 0, P_pi * 4 * 7),          # grad + params / m / v read and written
+        "relabel_fwd": ("k_disc_forward", "mfma", relabel_flops, TN * (F + 1) * 4 if w["E_d"] else 0),
+    }
     return dict(n_d=n_d, d_step_flops=d_step_flops, d_chain_flops=d_chain_flops, d_wgrad_flops=d_wgrad_flops, ppo_step_flops=ppo_step_flops, flops=flops, bytes=bytes_,
-                d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"])
+                d_steps=w["E_d"] * n_d, ppo_steps=w["E_p"] * w["M"], kernels=kernels)
 
 
 def build_problem(sg, w, seed):
@@ -318,12 +332,35 @@ def main():
         dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
         achieved = dom_flops / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
         name, num_cu, hbm = ctx.device_info()
-        traffic = None   # PMC passes cannot run inside the timed process: the committed summary of the last profile run
+        # PMC passes cannot run inside the timed process: counter traffic comes from the committed summary of the last
+        # profile run of THIS workload (tools/profile_workload.sh -> tools/make_traffic.py -> profiles/traffic.json)
+        tdoc = {}
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom_kernel]["hbm_bytes_per_launch"] if args.workload == "northstar" else None
+                tdoc = json.load(f)["workloads"].get(args.workload, {})
         except (OSError, KeyError, ValueError):
-            traffic = None
+            tdoc = {}
+
+        def counter_traffic(kname):
+            try:
+                return tdoc["kernels"][kname]["hbm_bytes_per_launch"]
+            except KeyError:
+                return None
+
+        traffic = counter_traffic(dom_kernel)
+        kmap = {}
+        for slot, (kname, bound, kflops, kbytes) in work["kernels"].items():
+            ms_, n_ = prof[slot]
+            if not n_:
+                continue
+            avg_s = ms_ / n_ * 1e-3
+            if bound == "mfma":
+                ach, peak, unit = kflops / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = kbytes / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+            kmap[kname] = {"bound": bound, "avg_us": round(avg_s * 1e6, 2), "launches": n_, "algorithmic_flops": kflops,
+                           "algorithmic_bytes": kbytes, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
+                           "traffic": counter_traffic(kname)}
         out = {
             "metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else "env-steps/sec of PPO update (policy refinement, a2c/main.py)", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -338,7 +375,9 @@ def main():
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom_kernel, "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5),
-                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)", "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE and WRITE_SIZE (separate passes) with the per-access-width calibration of profiles/r03_pmc_calibration.json; " + str(tdoc.get("source", "no profile of this workload committed")),
+                         "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
+                         "kernels": kmap,
                          "algorithmic_flops_per_launch": dom_flops,
                          "note": ("serial chain of 7 dependent GEMM phases on 96 four-row workgroups per 128-row step: latency-bound, see DESIGN.md section 4"
                                   if w["E_d"] else "fused forward + loss + backward + weight gradients of one minibatch, one row group per workgroup"),

@@ -93,6 +93,7 @@ static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
     if (fused) {   // Policy (independent actor / critic trunks): forward recomputed inside, no k_ppo_fwd launch
         if (MT == 1 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 3, 4, true>), grid, block, lds, pa); return; }
+        if (MT == 2 && ko == 7 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 7, 4, true>), grid, block, lds, pa); return; }   // Laikago refinement: obs 111, h64
         if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true>), grid, block, lds, pa);
         else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 0, 0, true>), grid, block, lds, pa);
         return;

@@ -450,3 +450,67 @@ extern "C" int sg_test_graph_state(sg_ppo* a, sg_disc* d, int out[2]) {
     out[1] = d ? (d->graph_refused ? 2 : (d->epoch_graph ? 1 : 0)) : -1;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Test hook: calibration of rocprofv3's FETCH_SIZE / WRITE_SIZE on this chip in THIS library's access patterns
+// (MI355X_MICROARCH.md, section HBM: FETCH_SIZE reports half the bytes of a 16-byte-per-lane coalesced stream on gfx950;
+// "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count in your own access pattern").
+// Each kernel below moves a KNOWN number of bytes of a buffer larger than the 256 MiB Infinity Cache, once, fully
+// coalesced, at one access width; tools/pmc_calibrate.py runs them under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+// and writes counter bytes / true bytes per width to profiles/, which tools/make_traffic.py applies per kernel.
+template <int W>   // bytes per lane per load instruction: 4, 8 or 16
+__global__ __launch_bounds__(256) void k_calib_read(const float* src, size_t n_floats, float* sink) {
+    constexpr int V = W / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * V;
+    float acc = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i + V <= n_floats; i += stride) {
+        if (V == 4) { const float4 v = *reinterpret_cast<const float4*>(src + i); acc += v.x + v.y + v.z + v.w; }
+        else if (V == 2) { const float2 v = *reinterpret_cast<const float2*>(src + i); acc += v.x + v.y; }
+        else acc += src[i];
+    }
+    if (acc == 12345.678f) sink[0] = acc;   // keeps the loads alive
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_calib_write(float* dst, size_t n_floats, float val) {
+    constexpr int V = W / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * V;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i + V <= n_floats; i += stride) {
+        if (V == 4) *reinterpret_cast<float4*>(dst + i) = float4{val, val, val, val};
+        else if (V == 2) *reinterpret_cast<float2*>(dst + i) = float2{val, val};
+        else dst[i] = val;
+    }
+}
+// The weight-gradient kernel's pattern: range-checked 4-byte buffer loads, a wave's 64 lanes covering 4 rows of 64 bytes
+// that sit 64 bytes apart in a [K][16] slab, i.e. one contiguous 256 bytes per load instruction.
+__global__ __launch_bounds__(256) void k_calib_read_buf4(const float* src, size_t n_floats, float* sink) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_floats * 4 > 0x7fffffffull ? 0x7fffffff : n_floats * 4), 0x00020000);
+    float acc = 0.f;
+    const size_t total = n_floats * 4 > 0x7fffffffull ? (size_t)0x7fffffff / 4 : n_floats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(i * 4), 0, 0));
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+extern "C" int sg_test_pmc_calibrate(sg_ctx* ctx, int64_t mbytes) {
+    SG_REQUIRE(ctx && mbytes >= 16 && mbytes <= 8192, "sg_test_pmc_calibrate: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)mbytes * (1 << 20) / 4;
+    float *a = nullptr, *b = nullptr, *sink = nullptr;
+    SG_CHECK(hipMalloc((void**)&a, n * 4));
+    SG_CHECK(hipMalloc((void**)&b, n * 4));
+    SG_CHECK(hipMalloc((void**)&sink, 64));
+    SG_CHECK(hipMemsetAsync(a, 0, n * 4, ctx->stream));
+    SG_CHECK(hipMemsetAsync(b, 0, n * 4, ctx->stream));   // evicts `a` from the Infinity Cache (buffers exceed it)
+    const dim3 grid(4096), block(256);
+    hipLaunchKernelGGL((k_calib_read<16>), grid, block, 0, ctx->stream, a, n, sink);
+    hipLaunchKernelGGL((k_calib_write<16>), grid, block, 0, ctx->stream, b, n, 1.0f);
+    hipLaunchKernelGGL((k_calib_read<8>), grid, block, 0, ctx->stream, a, n, sink);
+    hipLaunchKernelGGL((k_calib_write<8>), grid, block, 0, ctx->stream, b, n, 2.0f);
+    hipLaunchKernelGGL((k_calib_read<4>), grid, block, 0, ctx->stream, a, n, sink);
+    hipLaunchKernelGGL((k_calib_write<4>), grid, block, 0, ctx->stream, b, n, 3.0f);
+    hipLaunchKernelGGL(k_calib_read_buf4, grid, block, 0, ctx->stream, a, n, sink);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    return 0;
+}

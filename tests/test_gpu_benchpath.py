@@ -13,7 +13,7 @@ SG_PARITY_RECORD -- the committed record of a run is profiles/r03_parity.json):
 * Everything north_star pins at 1e-4 -- discriminator losses, relabelled rewards, GAE returns, Discriminator.returns, PPO
   losses -- at 1e-4 RELATIVE plus an absolute floor for the quantities that pass through zero (rewards are clipped to
   [-10, 10] and centred on 0; the action loss is a near-zero mean of +-advantage x ratio terms).  The floors are about
-  twice the deviation measured on MI355X, per workload.
+  three times the largest deviation measured on MI355X (1e-5 for rewards and returns, 2e-5 for the losses).
 * The discriminator trajectory (2,560 Adam steps per update) is smooth: weights are compared elementwise.
 * The POLICY trajectory is chaotic in float32: E x M clipped-surrogate Adam steps amplify a one-ulp difference in the rewards
   to ~3e-4 absolute on individual weights (~1 % of the update's L2 length at the north-star shape), measured with the oracle
@@ -38,15 +38,21 @@ from helpers import assert_close
 
 pytestmark = pytest.mark.gpu
 
-# Per workload: (policy rel-L2 gate, policy worst-entry gate) for ONE update from an identical start, then absolute floors
-# for rewards / returns / Discriminator.returns (all at rtol 1e-4) and for the PPO losses.  Float32 floors of the policy
-# trajectory (profiles/r03_parity_floor.json, perturbation 1e-6 / 1e-5): northstar 1.2e-2 / 2.8e-4, hopper 4.3e-2 / 5.0e-4,
-# laikago and refine: see that file.  Measured MI355X deviations: profiles/r03_parity.json.
+# Per workload.  pi_l2 / pi_worst: the policy after ONE update from an identical start (relative L2 of the update, worst
+# entry), at about twice that workload's float32 floor -- the oracle against itself under a 1e-6 / 1e-5 relative reward
+# perturbation, profiles/r03_parity_floor.json: northstar 1.2e-2 / 2.8e-4, hopper 4.3e-2 / 5.0e-4, laikago 7.0e-2 / 1.5e-3,
+# refine 1.9e-2 / 2.7e-4.  The other entries are the absolute floors that go with rtol = 1e-4: about three times the largest
+# deviation measured on MI355X (profiles/r03_parity.json: rewards 3.1e-6, GAE returns 3.8e-6, action loss 6.4e-6; the
+# discriminator's returns and losses need no floor at all); cont_ret_atol is for the CONTINUOUS track's second update, whose
+# value head has drifted with the policy (measured 7e-4 at hopper).  Laikago's loss floor is wider: its action loss after
+# 160 steps of the 55,557-parameter SplitPolicy sits 3.5e-5 from the oracle's (1e-3 of its value), four times the largest of
+# the oracle's three self-deviations (9e-6, profiles/r03_parity_floor.json) -- stated here rather than hidden in a loose
+# common gate; the same shape holds 1e-4 per step over a 16-step epoch (tests/test_gpu_fullsize.py).
 GATES = {
-    "northstar": dict(pi_l2=3e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
-    "hopper": dict(pi_l2=9e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
-    "laikago": dict(pi_l2=9e-2, pi_worst=1e-3, rew_atol=2e-4, ret_atol=2e-4, cont_ret_atol=5e-3, loss_atol=5e-5),
-    "refine": dict(pi_l2=3e-2, pi_worst=1e-3, rew_atol=0.0, ret_atol=2e-5, cont_ret_atol=5e-3, loss_atol=5e-5),
+    "northstar": dict(pi_l2=3e-2, pi_worst=1e-3, rew_atol=1e-5, ret_atol=1e-5, cont_ret_atol=2e-3, loss_atol=2e-5),
+    "hopper": dict(pi_l2=9e-2, pi_worst=1.2e-3, rew_atol=1e-5, ret_atol=1e-5, cont_ret_atol=2e-3, loss_atol=2e-5),
+    "laikago": dict(pi_l2=1.5e-1, pi_worst=3.2e-3, rew_atol=1e-5, ret_atol=1e-5, cont_ret_atol=2e-2, loss_atol=7e-5),
+    "refine": dict(pi_l2=4e-2, pi_worst=6e-4, rew_atol=0.0, ret_atol=1e-5, cont_ret_atol=2e-3, loss_atol=2e-5),
 }
 
 
@@ -173,6 +179,15 @@ def test_bench_path_two_updates_vs_oracle(workload):
         ro.sync_from_device()
         tag = f"{workload} update {it}: "
         rec = {}
+        record["updates"].append(rec)
+        failures = []
+
+        def gate_close(*a_, **k_):      # every gate of the update is evaluated (and the deviations recorded) before the test fails
+            try:
+                assert_close(*a_, **k_)
+            except AssertionError as exc:
+                failures.append(str(exc)[:400])
+
         if has_d:
             assert_close(out["r_sa"], r_sa, rtol=1e-9, atol=0, what=tag + "alive-bonus offset (device done count)")
             rec["rewards"] = _dev(_flat2(ro.rewards), rewards)
@@ -183,10 +198,10 @@ def test_bench_path_two_updates_vs_oracle(workload):
             assert_close(disc.returns.numpy()[:, 0], d_ret, rtol=1e-4, atol=gate["rew_atol"], what=tag + "Discriminator.returns")
             assert_close([out["gail_loss"], out["gail_loss_e"], out["gail_loss_p"]], dl, what=tag + "D losses of the last epoch")
             # trajectory level: 2,560 Adam steps (lr 1e-3) from identical starts: 1e-4 relative on the weights' own scale + a
-            # 2e-4 absolute floor for the entries near zero
+            # 1e-5 absolute floor for the entries near zero (measured: 1.9e-6)
             d_hip = disc.get_flat_params()
             rec["d_weights"] = _dev(d_hip, dp)
-            assert_close(d_hip, dp, rtol=1e-4, atol=2e-4, what=tag + "D weights after the update's discriminator steps")
+            assert_close(d_hip, dp, rtol=1e-4, atol=1e-5, what=tag + "D weights after the update's discriminator steps")
             assert np.abs(dp).max() > 0.1 and np.abs(d_hip - dp).max() < 1e-3 * np.abs(dp).max()
         p_hip = pol.get_flat_params()
         losses_hip = [out["value_loss"], out["action_loss"], out["dist_entropy"]]
@@ -204,13 +219,15 @@ def test_bench_path_two_updates_vs_oracle(workload):
                   f"PPO losses abs {['%.1e' % x for x in rec[name]['ppo_losses_abs']]}")
             strict = it == 0 or name == "reseeded"    # identical start of THIS update; otherwise two updates' drift compounds
             ret_atol = gate["ret_atol"] if strict else gate["cont_ret_atol"]
-            assert_close(_flat2(ro.value_preds)[T], tr["nv"], rtol=1e-4, atol=1e-5 if strict else gate["cont_ret_atol"],
-                         what=tag + name + " value_preds[T] = get_value(obs[T])")
-            assert_close(_flat2(ro.returns)[:T], tr["ret"][:T], rtol=1e-4, atol=ret_atol, what=tag + name + " GAE returns")
-            assert_close(losses_hip, tr["pl"], rtol=1e-4, atol=mult * gate["loss_atol"], what=tag + name + " PPO losses")
-            assert rel_l2 <= mult * gate["pi_l2"] and worst <= mult * gate["pi_worst"], (tag, name, rel_l2, worst)
+            gate_close(_flat2(ro.value_preds)[T], tr["nv"], rtol=1e-4, atol=1e-5 if strict else gate["cont_ret_atol"],
+                       what=tag + name + " value_preds[T] = get_value(obs[T])")
+            gate_close(_flat2(ro.returns)[:T], tr["ret"][:T], rtol=1e-4, atol=ret_atol, what=tag + name + " GAE returns")
+            gate_close(losses_hip, tr["pl"], rtol=1e-4, atol=mult * gate["loss_atol"], what=tag + name + " PPO losses")
+            if not (rel_l2 <= mult * gate["pi_l2"] and worst <= mult * gate["pi_worst"]):
+                failures.append(f"{tag}{name} policy trajectory: rel L2 {rel_l2:.3e} (gate {mult * gate['pi_l2']:.1e}), worst {worst:.3e} (gate {mult * gate['pi_worst']:.1e})")
             assert move > 0.1, "the update must move the policy far more than the tolerance"
-        record["updates"].append(rec)
+        _record(workload, record)
+        assert not failures, failures
 
         # ---- device after_update / count_dones against numpy on the downloaded buffers
         for name in ("obs", "obs_feat", "masks", "bad_masks"):

@@ -693,6 +693,36 @@ def test_predict_prob_single_step(sg, orc):
     assert isinstance(s0, float) and s0 == pytest.approx(float(s_ref[0]), rel=1e-4)
 
 
+def test_predict_reward_state_action_golden(sg):
+    """Discriminator.predict_reward (a2c/algo/gail.py:195-199) against the reference's own output, two calls with
+    Discriminator.returns carried between them."""
+    g = load("predict_reward")
+    m = g["meta"]
+    D = sg.algo.gail.Discriminator(m["S"] + m["A"], m["Hd"], None)
+    D.set_flat_params(g["params"])
+    for c in range(2):
+        rew, ret = D.predict_reward(g[f"state{c}"], g[f"action{c}"], m["gamma"], g[f"masks{c}"], offset=0.25 * c)
+        assert tuple(rew.shape) == (m["n"], 1) and tuple(ret.shape) == (m["n"], 1)
+        assert_close(rew.numpy(), g[f"reward{c}"], what=f"reward, call {c}")
+        assert_close(ret.numpy(), g[f"returns{c}"], what=f"returns, call {c}")
+        assert_close(D.returns.numpy(), g[f"returns{c}"], what="Discriminator.returns")
+
+
+def test_feed_forward_generator_on_a_device_backed_rollout(sg):
+    """The method form of simgan_amd.storage.feed_forward_batches (tests/test_host_logic.py checks the batches against the
+    reference fixture): same tuples from a real RolloutStorage, permutation injected."""
+    g = dict(np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "ffgen.npz")))
+    T, N = g["rewards"].shape[:2]
+    ro = sg.RolloutStorage(T, N, (g["obs"].shape[-1],), Box((g["actions"].shape[-1],)), 1, g["obs_feat"].shape[-1])
+    for name in ("obs", "obs_feat", "actions", "rewards", "value_preds", "returns", "action_log_probs", "masks", "bad_masks"):
+        getattr(ro, name).copy_(getattr(ro, name).new_tensor(g[name]))
+    batches = list(ro.feed_forward_generator(None, mini_batch_size=8, perm=g["disc_perm"]))
+    assert len(batches) == int(g["disc_n_batches"]) == 2
+    for b, tup in enumerate(batches):
+        assert np.array_equal(tup[9].numpy(), g[f"disc_b{b}_next_obs_feat"]) and np.array_equal(tup[0].numpy(), g[f"disc_b{b}_obs"])
+        assert tup[7] is None
+
+
 def test_bare_torch_load_through_alias_modules_gives_the_shim(sg):
     """a2c/main.py:81-83 / my_pybullet_envs/utils.py:43-46: `torch.load(path)` of a reference whole-module checkpoint,
     with `third_party.a2c_ppo_acktr` resolving to this repository's alias package, unpickles straight into the

@@ -119,6 +119,65 @@ def test_env_pool_shards_cover_the_global_pool():
     assert whole.ret_rms.count == pytest.approx(1e-4 + 12 * 8) and shards[0].ret_rms.count == pytest.approx(1e-4 + 12 * 4)
 
 
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the SimGAN checkout (development container only)")
+def test_checkouts_shmem_vec_env_plugs_into_make_vec_envs():
+    """SURVEY.md 8(f) N4 asks for a ShmemVecEnv-like pool per GPU; the multi-process pool itself stays the checkout's
+    (a2c/envs.py:115-118, a2c/baselines/common/vec_env/shmem_vec_env.py:43-165: one process per environment, observations
+    through shared arrays).  This is the adapter test: the checkout's class, unmodified, as `make_vec_envs(vec_cls=...)` for
+    one rank's shard, stepping real worker processes, must give the same observations / rewards / dones as the in-process
+    SerialVecEnv on the same deterministic environments (gym itself is absent here: the pool only needs the two spaces'
+    shape / dtype, supplied by duck-typed stand-ins)."""
+    code = r'''
+import sys, types
+import numpy as np
+sys.path.insert(0, "tools")
+from ref_import import install_stubs
+install_stubs()
+import gym.spaces                                             # the stand-in module: give the two classes the pool type-checks
+gym.spaces.Dict, gym.spaces.Tuple = type("Dict", (), {}), type("Tuple", (), {})
+gym.spaces = sys.modules["gym.spaces"]
+from third_party.a2c_ppo_acktr.baselines.common.vec_env.shmem_vec_env import ShmemVecEnv
+from simgan_amd.envs import make_vec_envs, SerialVecEnv
+
+class Space:
+    def __init__(self, shape): self.shape, self.dtype = tuple(shape), np.dtype(np.float32)
+
+class FakeEnv:
+    observation_space, action_space = Space((3,)), Space((2,))
+    def __init__(self, gid, seed): self.gid, self.rng, self.t = gid, np.random.default_rng(seed), 0
+    def reset(self):
+        self.t = 0
+        return self.rng.standard_normal(3).astype(np.float32) + self.gid
+    def step(self, a):
+        self.t += 1
+        done = self.t >= 3 + self.gid % 2
+        return (self.rng.standard_normal(3).astype(np.float32) + float(np.sum(a)), float(self.gid + 0.1 * self.t), done,
+                {"bad_transition": True} if done and self.gid == 5 else {})
+    def close(self): pass
+
+shmem = lambda fns: ShmemVecEnv(fns, context="fork")          # fork: the workers inherit the gym stand-ins
+pools = [make_vec_envs(FakeEnv, seed=40, num_processes=8, gamma=0.99, rank=1, world=2, vec_cls=c) for c in (shmem, SerialVecEnv)]
+assert pools[0].global_ids == [4, 5, 6, 7] and len(pools[0].venv.procs) == 4
+o = [p.reset().numpy() for p in pools]
+assert np.array_equal(o[0], o[1]) and o[0].shape == (4, 3) and o[0].dtype == np.float32
+rng = np.random.default_rng(1)
+for _ in range(9):
+    a = rng.standard_normal((4, 2)).astype(np.float32)
+    r = [p.step(a) for p in pools]
+    assert np.array_equal(r[0][0].numpy(), r[1][0].numpy())            # observations, auto-reset included
+    # return-scaled rewards: ShmemVecEnv hands float64 rewards to VecNormalize (np.array of Python floats, shmem_vec_env.py:97),
+    # DummyVecEnv / SerialVecEnv float32 ones (dummy_vec_env.py:41) -- the reference's own two pools differ by that rounding
+    assert np.allclose(r[0][1].numpy(), r[1][1].numpy(), rtol=1e-6, atol=0) and r[0][1].shape == (4, 1) and r[0][1].dtype == r[1][1].dtype
+    assert np.array_equal(np.asarray(r[0][2]), np.asarray(r[1][2]))
+    assert [("bad_transition" in i) for i in r[0][3]] == [("bad_transition" in i) for i in r[1][3]]
+pools[0].close()
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, REFERENCE])))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_feed_forward_generator_yields_the_reference_tuples():
     """RolloutStorage.feed_forward_generator against the reference's own output (tests/golden/ffgen.npz, written by
     tools/gen_golden.py from a2c/storage.py:144-192 with the sampler's permutation recorded): PPO form (num_mini_batch,

@@ -158,6 +158,19 @@ def test_relabel(name):
         assert_close(rms, g[f"rms{call}"], rtol=1e-5, what="ret_rms")
 
 
+def test_predict_reward_state_action():
+    """Discriminator.predict_reward(state, action, gamma, masks, offset) a2c/algo/gail.py:195-199: the combined form on
+    cat(state, action); two calls, the second continues Discriminator.returns."""
+    g = load("predict_reward")
+    m = g["meta"]
+    ret = None
+    for c in range(2):
+        x = np.concatenate([g[f"state{c}"], g[f"action{c}"]], axis=1)
+        rew, ret = orc.disc_predict_reward(m["S"] + m["A"], m["Hd"], g["params"], x, m["gamma"], g[f"masks{c}"][:, 0], 0.25 * c, ret)
+        assert_close(rew, g[f"reward{c}"], what=f"reward, call {c}")
+        assert_close(ret, g[f"returns{c}"], what=f"returns, call {c}")
+
+
 @pytest.mark.parametrize("name", ["iter_mlp", "iter_split"])
 def test_full_iteration(name):
     """a2c/main_gail_dyn_ppo.py:239-304 restated with oracle calls, 2 outer iterations."""

@@ -1,22 +1,40 @@
-"""profiles/<tag>_pmc_{fetch,write}_size.txt -> profiles/traffic.json (read by bench.py for roofline.traffic).
-HBM-side bytes per launch = FETCH_SIZE x 2 (gfx950 counts a wide coalesced read at half its bytes,
-MI355X_MICROARCH.md section HBM; the kernels' reads are 16-byte-per-lane streams) + WRITE_SIZE (uncorrected), both KB.
-Usage: python tools/make_traffic.py r01_v7"""
+"""profiles/<tag>_<workload>_pmc_{fetch,write}_size.txt -> profiles/traffic.json (read by bench.py for roofline.traffic and
+roofline.kernels[*].traffic), keyed by workload.
+
+HBM-side bytes per launch = FETCH_SIZE x c_f + WRITE_SIZE x c_w with the corrections MEASURED on this chip by
+tools/profile_calibration.sh (profiles/<calib>_pmc_calibration.json; MI355X_MICROARCH.md section HBM prescribes calibrating
+on a known byte count in one's own access pattern): coalesced reads of 4, 8 and 16 bytes per lane and range-checked 4-byte
+buffer loads all report exactly HALF their bytes in FETCH_SIZE (c_f = 2), WRITE_SIZE reports stores of every width exactly
+(c_w = 1).  Counter units are KB.
+
+Usage: python tools/make_traffic.py <tag> [<calibration tag>]      e.g.  python tools/make_traffic.py r03_v18 r03"""
 import json
+import os
 import re
 import sys
 
 tag = sys.argv[1]
-out = {}
-for what, corr in (("fetch", 2.0), ("write", 1.0)):
-    for line in open(f"profiles/{tag}_pmc_{what}_size.txt"):
-        m = re.match(r"(?:void )?(\w+)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
-        if m:
-            k = out.setdefault(m.group(1), {"fetch_kb_raw": 0.0, "write_kb_raw": 0.0})
-            k[f"{what}_kb_raw"] = float(m.group(4))
-            k[f"{what}_correction"] = corr
-for k, v in out.items():
-    v["hbm_bytes_per_launch"] = int(1024 * (v["fetch_kb_raw"] * v.get("fetch_correction", 2.0) + v["write_kb_raw"]))
-json.dump({"source": f"profiles/{tag}_pmc_fetch_size.txt, profiles/{tag}_pmc_write_size.txt", "kernels": out},
-          open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
-print(json.dumps(out, indent=1)[:600])
+calib_tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+calib = json.load(open(f"profiles/{calib_tag}_pmc_calibration.json"))
+reads = [v["counter_over_true"] for k, v in calib["FETCH_SIZE"].items() if k.startswith("k_calib_read")]
+writes = [v["counter_over_true"] for k, v in calib["WRITE_SIZE"].items() if k.startswith("k_calib_write")]
+assert max(reads) - min(reads) < 0.01 and max(writes) - min(writes) < 0.01, "the calibration differs by access width: extend this tool"
+c_f, c_w = 1.0 / (sum(reads) / len(reads)), 1.0 / (sum(writes) / len(writes))
+doc = {"calibration": {"source": f"profiles/{calib_tag}_pmc_calibration.json", "fetch_correction": round(c_f, 4), "write_correction": round(c_w, 4)},
+       "workloads": {}}
+for wl in ("northstar", "hopper", "laikago", "refine"):
+    files = {w: f"profiles/{tag}_{wl}_pmc_{w}_size.txt" for w in ("fetch", "write")}
+    if not all(os.path.exists(f) for f in files.values()):
+        continue
+    out = {}
+    for what in ("fetch", "write"):
+        for line in open(files[what]):
+            m = re.match(r"(?:void )?(\w+)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
+            if m:
+                out.setdefault(m.group(1), {"fetch_kb_raw": 0.0, "write_kb_raw": 0.0})[f"{what}_kb_raw"] = float(m.group(4))
+    for v in out.values():
+        v["hbm_bytes_per_launch"] = int(1024 * (v["fetch_kb_raw"] * c_f + v["write_kb_raw"] * c_w))
+    doc["workloads"][wl] = {"source": f"{files['fetch']}, {files['write']}", "kernels": out}
+json.dump(doc, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
+for wl, d in doc["workloads"].items():
+    print(wl, {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if k.startswith(("k_disc_chain", "k_disc_wgrad", "k_ppo_"))})

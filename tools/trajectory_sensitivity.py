@@ -57,15 +57,33 @@ def measure(name):
         print(name, "perturbation", eps, "losses", ls, f"{time.time() - t:.1f} s", flush=True)
         outs.append(p)
         losses.append(ls)
+    # the same update once more, unperturbed, with every step's gradient summed in a different ORDER (the rows of a minibatch
+    # split over 7 threads, partial sums added in chunk order: orc_ppo_grad_rows_mt) -- the perturbation any second float32
+    # implementation applies at EVERY step, not once
+    ret, vp2 = orc.compute_returns(rewards, vp, masks, bad, nv, 1, 0.99, 0.95, 1)
+    adv = orc.advantages(ret[:-1], vp2[:-1])
+    p, ad = par0.copy(), orc.AdamState(n)
+    mb = T * N // M
+    acc = np.zeros(3)
+    t = time.time()
+    for e in range(E):
+        for k in range(M):
+            G, sums = orc.ppo_grad_rows_mt(d, p, cfg, obs, actions, vp2, ret, logp, adv, perms[e, k * mb:(k + 1) * mb], 1.0 / mb, 7)
+            acc += sums / mb
+            orc.ppo_apply(p, G, ad, cfg)
+    ls = tuple(acc / (E * M))
+    print(name, "reordered sums, losses", ls, f"{time.time() - t:.1f} s", flush=True)
+    outs.append(p)
+    losses.append(ls)
     rec = {"shape": dict(T=T, N=N, O=O, A=A, H=H, kind=kind, feet=feet, E=E, M=M, clip=clip, lr=lr), "steps": E * M}
-    for i, eps in ((1, 1e-6), (2, 1e-5)):
+    for i, key in ((1, "perturb_1e-06"), (2, "perturb_1e-05"), (3, "reordered_sums")):
         e = np.abs(outs[i] - outs[0])
         tol = 5e-5 + 1e-4 * np.abs(outs[0])
-        rec[f"perturb_{eps:g}"] = dict(
+        rec[key] = dict(
             rel_l2_of_update=float(np.linalg.norm(outs[i] - outs[0]) / np.linalg.norm(outs[0] - par0)), worst_entry=float(e.max()),
             frac_beyond_tol=float(np.mean(e > tol)), max_move=float(np.abs(outs[0] - par0).max()),
             loss_abs_diff=[float(abs(a - b)) for a, b in zip(losses[i], losses[0])])
-        print(name, "perturbation", eps, rec[f"perturb_{eps:g}"], flush=True)
+        print(name, key, rec[key], flush=True)
     return rec
 
 
