@@ -187,7 +187,9 @@ int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
  * With a communicator of world > 1 the injected policy_perm is the reference's draw at num_processes = world*N
  * ([T*N*world] ids in its numbering t*(N*world) + rank*N + n), the same arrays on every rank, in both data-parallel
  * modes; n_d = min(n_expert/batch, T*N*world/batch).  Sharded mode takes the three arrays together or none.
- * out3 = {mean(gail_loss+grad_pen), mean expert_loss, mean policy_loss}; *n_steps = n_d.
+ * out3 = {mean(gail_loss+grad_pen), mean expert_loss, mean policy_loss}; *n_steps = n_d.  out3 may be NULL when the caller
+ * has no use for this epoch's losses (the reference's main keeps only the last epoch's, a2c/main_gail_dyn_ppo.py:255-256):
+ * the call then returns as soon as the epoch is queued instead of waiting for it.
  * n_expert < batch_size is an error (the reference raises on the size mismatch). */
 int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm, int64_t n_expert_perm,
                             const int64_t *policy_perm, int64_t n_policy_perm, const float *alpha, int64_t n_alpha,

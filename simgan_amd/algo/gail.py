@@ -140,9 +140,11 @@ class Discriminator(object):
         return ep, pp, al
 
     # ---------------------------------------------------------------------- updates
-    def update_gail_dyn(self, expert_loader, rollouts, expert_perm=None, policy_perm=None, alpha=None):
+    def update_gail_dyn(self, expert_loader, rollouts, expert_perm=None, policy_perm=None, alpha=None, fetch_losses=True):
         """a2c/algo/gail.py:154-193, one epoch -> (loss, expert_loss, policy_loss) means.
-        expert_perm / policy_perm / alpha inject the reference's RNG artefacts (parity tests)."""
+        expert_perm / policy_perm / alpha inject the reference's RNG artefacts (parity tests).
+        fetch_losses=False: return None as soon as the epoch is queued on the device (a driver that keeps only the last
+        epoch's losses, like a2c/main_gail_dyn_ppo.py:255-256, need not wait for the earlier ones)."""
         B = self._bind_loader(expert_loader)
         rollouts._push([_lib.F_OBS_FEAT])
         out = (C.c_float * 3)()
@@ -154,9 +156,10 @@ class Discriminator(object):
         # union of every rank's rows in the reference's numbering, in both data-parallel modes
         self._calls += 1
         _lib.check(self.lib.sg_disc_update_gail_dyn(
-            self.h, rollouts.h, B, *self._draw_args(ep, pp, al), (self.seed + self._calls) & (2 ** 64 - 1), out, C.byref(nst)))
+            self.h, rollouts.h, B, *self._draw_args(ep, pp, al), (self.seed + self._calls) & (2 ** 64 - 1),
+            out if fetch_losses else None, C.byref(nst)))
         self.last_n_steps = nst.value
-        return float(out[0]), float(out[1]), float(out[2])
+        return (float(out[0]), float(out[1]), float(out[2])) if fetch_losses else None
 
     def update(self, expert_loader, rollouts, obsfilt=None, is_gail_dyn=False, a_dim=None,
                expert_perm=None, policy_perm=None, alpha=None):

@@ -29,6 +29,15 @@ void sg_set_error(const char* fmt, ...);
         }                            \
     } while (0)
 
+// Synchronous host<->device copy on the context's OWN stream.  The runtime's synchronous hipMemcpy goes through the legacy
+// stream, which the runtime refuses (and which invalidates the capture) while any stream of the process is capturing --
+// contexts driven from several host threads would break each other's graph captures.
+#define SG_COPY_SYNC(ctx, dst, src, bytes, kind)                                         \
+    do {                                                                                 \
+        SG_CHECK(hipMemcpyAsync(dst, src, bytes, kind, (ctx)->stream));                  \
+        SG_CHECK(hipStreamSynchronize((ctx)->stream));                                   \
+    } while (0)
+
 #define SG_TRY(expr)            \
     do {                        \
         int _r = (expr);        \
@@ -234,22 +243,41 @@ __device__ __forceinline__ void sg_opt_prepare(SgOptState* st, int t) {
 #endif
 
 // Capture `enqueue()` (kernel launches and, with a communicator, RCCL collectives on ctx->stream) into a graph and
-// instantiate it.  RCCL supports stream capture, but whether a given build / topology accepts it is only known at run
-// time: any failure ends the capture, clears the error and returns 1 ("run it eagerly instead"); 0 = *exec is ready.
+// instantiate it.  Whether a capture goes through is only known at run time (an RCCL build / topology may refuse it; so may
+// the runtime when other host threads are busy with it): any failure ends the capture, is reported ONCE on stderr with the
+// HIP error that caused it, and returns 1 ("run it eagerly instead" -- the caller then stays on direct launches for that
+// object); 0 = *exec is ready.  Captures are serialised within the process and use the relaxed capture mode: contexts
+// driven from several host threads (tests/test_gpu_world.py) otherwise invalidate each other's captures with their own
+// allocations and copies.
+#include <stdio.h>
+
+#include <mutex>
+inline std::mutex& sg_capture_mutex() { static std::mutex m; return m; }
 template <typename F>
 static inline int sg_try_capture(sg_ctx* ctx, hipGraphExec_t* exec, F&& enqueue) {
+    std::lock_guard<std::mutex> lock(sg_capture_mutex());
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return 1; }
-    const int rc = enqueue();
-    const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-    if (rc != 0 || ce != hipSuccess || !graph) {
+    auto refuse = [&](const char* what, hipError_t e, int rc) {
+        static bool told = false;
+        if (!told) {
+            fprintf(stderr, "[simgan_hip] graph capture not used (%s: %s%s); falling back to direct launches\n", what,
+                    e != hipSuccess ? hipGetErrorString(e) : "no HIP error", rc != 0 ? ", enqueue reported an error" : "");
+            told = true;
+        }
         (void)hipGetLastError();
-        if (graph) (void)hipGraphDestroy(graph);
         return 1;
+    };
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return refuse("hipStreamBeginCapture", e, 0);
+    const int rc = enqueue();
+    e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != 0 || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return refuse("hipStreamEndCapture", e, rc);
     }
-    const hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; return 1; }
+    if (e != hipSuccess) { *exec = nullptr; return refuse("hipGraphInstantiate", e, 0); }
     return 0;
 }
 

@@ -286,7 +286,7 @@ static int disc_put(sg_disc* d, float* dev, const float* flat, int64_t n, const 
     std::vector<float> padded(d->desc.total, 0.f);
     sg_disc_pad(d->desc, flat, padded.data());
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    SG_CHECK(hipMemcpy(dev, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
+    SG_COPY_SYNC(d->ctx, dev, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice);
     return 0;
 }
 static int disc_get(sg_disc* d, const float* dev, float* flat, int64_t n, const char* who) {
@@ -294,7 +294,7 @@ static int disc_get(sg_disc* d, const float* dev, float* flat, int64_t n, const 
                (long long)sg_disc_flat_count(d->desc), (long long)n);
     std::vector<float> padded(d->desc.total);
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    SG_CHECK(hipMemcpy(padded.data(), dev, sizeof(float) * padded.size(), hipMemcpyDeviceToHost));
+    SG_COPY_SYNC(d->ctx, padded.data(), dev, sizeof(float) * padded.size(), hipMemcpyDeviceToHost);
     sg_disc_unpad(d->desc, padded.data(), flat);
     return 0;
 }
@@ -324,7 +324,7 @@ extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int6
     SG_REQUIRE(step >= 0 && step < (1ll << 30), "sg_disc_set_adam: step out of range");
     d->opt_t = step;
     const int t0 = (int)step;
-    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(d->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice));
+    SG_COPY_SYNC(d->ctx, &reinterpret_cast<SgOptState*>(d->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice);
     return 0;
 }
 
@@ -334,7 +334,7 @@ extern "C" int sg_disc_set_expert(sg_disc* d, const float* expert, int64_t n_row
     if (d->d_expert) SG_CHECK(hipFree(d->d_expert));
     const size_t bytes = sizeof(float) * (size_t)n_rows * d->desc.F;
     SG_CHECK(hipMalloc((void**)&d->d_expert, bytes));
-    SG_CHECK(hipMemcpy(d->d_expert, expert, bytes, hipMemcpyHostToDevice));
+    SG_COPY_SYNC(d->ctx, d->d_expert, expert, bytes, hipMemcpyHostToDevice);
     d->n_expert = n_rows;
     return 0;
 }
@@ -579,7 +579,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     // SG_DISC_GRAPH_COMM=0 or the RCCL build refuses the capture.
     const char* genv = getenv("SG_DISC_GRAPH");
     const char* gcenv = getenv("SG_DISC_GRAPH_COMM");
-    const bool comm_ok = !sharded || (!d->graph_refused && sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0")));
+    const bool comm_ok = !d->graph_refused && (!sharded || (sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0"))));
     bool use_graph = comm_ok && !owned && !ctx->profile && !d->d_dbg && !(genv && !strcmp(genv, "0"));
     if (use_graph) {
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
@@ -590,8 +590,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
             if (sg_try_capture(ctx, &d->epoch_graph, enqueue_epoch) != 0) {
-                SG_REQUIRE(sharded, "sg_disc_update_gail_dyn: graph capture of the epoch failed");
-                d->graph_refused = true;
+                d->graph_refused = true;   // reported once on stderr; this object launches kernel by kernel from now on
                 use_graph = false;
             } else {
                 memcpy(d->epoch_graph_key, key, sizeof key);
@@ -602,6 +601,11 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     if (!use_graph) SG_TRY(enqueue_epoch());
     SG_CHECK(hipGetLastError());
     const auto t_enq1 = std::chrono::steady_clock::now();
+    d->opt_t += n_d;
+    // out3 == NULL: the caller does not want this epoch's losses (the reference's main keeps only the last epoch's,
+    // a2c/main_gail_dyn_ppo.py:255-256) -- the epoch stays queued, the host does not wait for it, and the next epoch's launch
+    // overlaps its execution.  Everything the next call touches is ordered behind it on the library's stream.
+    if (!out3) return 0;
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, d->d_loss_acc, acc, 3));
     if (dbg_timing) {
@@ -611,14 +615,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                 std::chrono::duration<double, std::milli>(t_done - t_enq1).count());
     }
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / n_d);
-    d->opt_t += n_d;
     return 0;
 }
 
 extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size, const int64_t* expert_perm, int64_t n_expert_perm,
                                        const int64_t* policy_perm, int64_t n_policy_perm, const float* alpha, int64_t n_alpha,
                                        uint64_t seed, float out3[3], int* n_steps) {
-    SG_REQUIRE(d && r && out3, "sg_disc_update_gail_dyn: NULL argument");
+    SG_REQUIRE(d && r, "sg_disc_update_gail_dyn: NULL argument");
     SG_REQUIRE(r->F == d->desc.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
     // policy rows = next_obs_feat = obs_feat[1:]   (a2c/storage.py:172, a2c/algo/gail.py:165)
     return disc_update_core(d, r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F, (int64_t)r->T * r->N, r->N, batch_size,
@@ -628,7 +631,7 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
 extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t n_rows, int n_cols, int batch_size,
                                    const int64_t* expert_perm, int64_t n_expert_perm, const int64_t* policy_perm, int64_t n_policy_perm,
                                    const float* alpha, int64_t n_alpha, uint64_t seed, float out3[3], int* n_steps) {
-    SG_REQUIRE(d && policy_rows && out3 && n_rows > 0, "sg_disc_update_rows: bad argument");
+    SG_REQUIRE(d && policy_rows && n_rows > 0, "sg_disc_update_rows: bad argument");
     sg_ctx* ctx = d->ctx;
     SG_CHECK(hipSetDevice(ctx->device));
     SG_TRY(ensure_cap(&d->d_rows, &d->rows_cap, n_rows * d->desc.F, ctx->stream));
@@ -705,9 +708,9 @@ extern "C" int sg_disc_last_draws(sg_disc* d, int64_t* expert_perm, int64_t* pol
     if (counts3) for (int i = 0; i < 3; ++i) counts3[i] = d->last_draws[i];
     SG_CHECK(hipSetDevice(d->ctx->device));
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    if (expert_perm) SG_CHECK(hipMemcpy(expert_perm, d->d_eperm, sizeof(int64_t) * d->last_draws[0], hipMemcpyDeviceToHost));
-    if (policy_perm) SG_CHECK(hipMemcpy(policy_perm, d->d_pperm, sizeof(int64_t) * d->last_draws[1], hipMemcpyDeviceToHost));
-    if (alpha) SG_CHECK(hipMemcpy(alpha, d->d_alpha, sizeof(float) * d->last_draws[2], hipMemcpyDeviceToHost));
+    if (expert_perm) SG_COPY_SYNC(d->ctx, expert_perm, d->d_eperm, sizeof(int64_t) * d->last_draws[0], hipMemcpyDeviceToHost);
+    if (policy_perm) SG_COPY_SYNC(d->ctx, policy_perm, d->d_pperm, sizeof(int64_t) * d->last_draws[1], hipMemcpyDeviceToHost);
+    if (alpha) SG_COPY_SYNC(d->ctx, alpha, d->d_alpha, sizeof(float) * d->last_draws[2], hipMemcpyDeviceToHost);
     return 0;
 }
 
@@ -778,11 +781,11 @@ extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, 
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
     if (enable && !d->d_dbg) {
         SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 512));
-        SG_CHECK(hipMemset(d->d_dbg, 0, sizeof(long long) * 32 * 512));
+        SG_CHECK(hipMemsetAsync(d->d_dbg, 0, sizeof(long long) * 32 * 512, d->ctx->stream)); SG_CHECK(hipStreamSynchronize(d->ctx->stream));
     }
     if (out && d->d_dbg) {
         SG_REQUIRE(n_blocks <= 512, "sg_test_disc_phase_times: at most 512 blocks");
-        SG_CHECK(hipMemcpy(out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));   // n_blocks = 512: + k_disc_wgrad stamps
+        SG_COPY_SYNC(d->ctx, out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost);   // n_blocks = 512: + k_disc_wgrad stamps
     }
     if (!enable && d->d_dbg) { SG_CHECK(hipFree(d->d_dbg)); d->d_dbg = nullptr; }
     return 0;

@@ -248,7 +248,7 @@ extern "C" int sg_policy_set_params(sg_policy* p, const float* flat, int64_t n) 
     std::vector<float> padded(p->desc.total, 0.f);
     sg_policy_pad(p->desc, flat, padded.data());
     SG_CHECK(hipStreamSynchronize(p->ctx->stream));
-    SG_CHECK(hipMemcpy(p->d_params, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
+    SG_COPY_SYNC(p->ctx, p->d_params, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice);
     return 0;
 }
 
@@ -258,7 +258,7 @@ extern "C" int sg_policy_get_params(sg_policy* p, float* flat, int64_t n) {
                (long long)sg_policy_flat_count(p->desc), (long long)n);
     std::vector<float> padded(p->desc.total);
     SG_CHECK(hipStreamSynchronize(p->ctx->stream));
-    SG_CHECK(hipMemcpy(padded.data(), p->d_params, sizeof(float) * padded.size(), hipMemcpyDeviceToHost));
+    SG_COPY_SYNC(p->ctx, padded.data(), p->d_params, sizeof(float) * padded.size(), hipMemcpyDeviceToHost);
     sg_policy_unpad(p->desc, padded.data(), flat);
     return 0;
 }

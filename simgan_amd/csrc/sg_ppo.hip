@@ -165,7 +165,7 @@ extern "C" int sg_ppo_last_perms(sg_ppo* a, int64_t* perms, int64_t count) {
                (long long)a->last_perm_count, (long long)count);
     SG_CHECK(hipSetDevice(a->ctx->device));
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
-    SG_CHECK(hipMemcpy(perms, a->d_perms, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
+    SG_COPY_SYNC(a->ctx, perms, a->d_perms, sizeof(int64_t) * count, hipMemcpyDeviceToHost);
     return 0;
 }
 
@@ -175,8 +175,8 @@ extern "C" int sg_ppo_get_adam(sg_ppo* a, float* m, float* v, int64_t n, int64_t
     SG_REQUIRE(n == sg_policy_flat_count(d), "sg_ppo_get_adam: bad length");
     std::vector<float> pm(d.total), pv(d.total);
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
-    SG_CHECK(hipMemcpy(pm.data(), a->d_m, sizeof(float) * d.total, hipMemcpyDeviceToHost));
-    SG_CHECK(hipMemcpy(pv.data(), a->d_v, sizeof(float) * d.total, hipMemcpyDeviceToHost));
+    SG_COPY_SYNC(a->ctx, pm.data(), a->d_m, sizeof(float) * d.total, hipMemcpyDeviceToHost);
+    SG_COPY_SYNC(a->ctx, pv.data(), a->d_v, sizeof(float) * d.total, hipMemcpyDeviceToHost);
     sg_policy_unpad(d, pm.data(), m);
     sg_policy_unpad(d, pv.data(), v);
     *step = a->opt_t;
@@ -193,9 +193,9 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     SG_REQUIRE(step >= 0 && step < (1ll << 30), "sg_ppo_set_adam: step out of range");
     const int t0 = (int)step;
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
-    SG_CHECK(hipMemcpy(a->d_m, pm.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
-    SG_CHECK(hipMemcpy(a->d_v, pv.data(), sizeof(float) * d.total, hipMemcpyHostToDevice));
-    SG_CHECK(hipMemcpy(&reinterpret_cast<SgOptState*>(a->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice));
+    SG_COPY_SYNC(a->ctx, a->d_m, pm.data(), sizeof(float) * d.total, hipMemcpyHostToDevice);
+    SG_COPY_SYNC(a->ctx, a->d_v, pv.data(), sizeof(float) * d.total, hipMemcpyHostToDevice);
+    SG_COPY_SYNC(a->ctx, &reinterpret_cast<SgOptState*>(a->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice);
     a->opt_t = step;
     return 0;
 }
@@ -401,7 +401,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // RCCL build refuses falls back to direct launches.
     const char* genv = getenv("SG_PPO_GRAPH");
     const char* gcenv = getenv("SG_PPO_GRAPH_COMM");
-    const bool comm_ok = !ctx->use_comm || (!a->graph_refused && sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0")));
+    const bool comm_ok = !a->graph_refused && (!ctx->use_comm || (sg_comm_graph_ok(ctx) && !(gcenv && !strcmp(gcenv, "0"))));
     bool use_graph = comm_ok && !owned && !ctx->profile && !a->d_dbg && !(genv && !strcmp(genv, "0"));
     if (use_graph) {
         uint32_t fbits[6];
@@ -417,8 +417,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
-                SG_REQUIRE(ctx->use_comm, "sg_ppo_update: graph capture of the optimizer steps failed");
-                a->graph_refused = true;   // RCCL would not be captured here: direct launches from now on
+                a->graph_refused = true;   // reported once on stderr: direct launches from now on
                 use_graph = false;
             } else {
                 memcpy(a->steps_graph_key, key, sizeof key);
@@ -442,11 +441,11 @@ extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, in
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));
     if (enable && !a->d_dbg) {
         SG_CHECK(hipMalloc((void**)&a->d_dbg, sizeof(long long) * 16 * 1024));
-        SG_CHECK(hipMemset(a->d_dbg, 0, sizeof(long long) * 16 * 1024));
+        SG_CHECK(hipMemsetAsync(a->d_dbg, 0, sizeof(long long) * 16 * 1024, a->ctx->stream)); SG_CHECK(hipStreamSynchronize(a->ctx->stream));
     }
     if (out && a->d_dbg) {
         SG_REQUIRE(n_blocks <= 1024, "sg_test_ppo_phase_times: at most 1024 blocks");
-        SG_CHECK(hipMemcpy(out, a->d_dbg, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost));
+        SG_COPY_SYNC(a->ctx, out, a->d_dbg, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost);
     }
     if (!enable && a->d_dbg) { SG_CHECK(hipFree(a->d_dbg)); a->d_dbg = nullptr; }
     return 0;
@@ -467,11 +466,11 @@ extern "C" int sg_test_rng(sg_ctx* ctx, int kind, int64_t n, uint64_t seed, void
     if (kind == 0) {
         SG_TRY(sg_fill_perm(ctx, (int64_t*)dev, n, seed, 3));
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        SG_CHECK(hipMemcpy(out, dev, (size_t)n * 8, hipMemcpyDeviceToHost));
+        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 8, hipMemcpyDeviceToHost);
     } else {
         hipLaunchKernelGGL(k_test_rng, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)dev, n, seed, kind);
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        SG_CHECK(hipMemcpy(out, dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 4, hipMemcpyDeviceToHost);
     }
     (void)hipFree(dev);
     return 0;

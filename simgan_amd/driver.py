@@ -75,8 +75,9 @@ class GailDynLearner(object):
         if self.use_linear_lr_decay:            # :203-207
             update_linear_schedule(self.agent.optimizer, self.j, self.num_updates, self.lr)
         gail = None
-        for _ in range(self.gail_epoch):        # :255-256
-            gail = self.discr.update_gail_dyn(self.loader, ro)
+        for e in range(self.gail_epoch):        # :255-256 -- the reference keeps the last epoch's losses only
+            last = e == self.gail_epoch - 1
+            gail = self.discr.update_gail_dyn(self.loader, ro, **({} if last else {"fetch_losses": False}))
         if ro.device_resident:
             dones = C.c_double(0)
             _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))   # all ranks (RCCL) when world > 1

@@ -62,9 +62,10 @@ def run_ranks(world, fn, timeout_s=600):
     for t in threads:
         t.join(timeout_s)
     assert not any(t.is_alive() for t in threads), "a rank is still running (loopback collective stuck?)"
-    for r, e in enumerate(err):
-        if e is not None:
-            raise AssertionError(f"rank {r}: {type(e).__name__}: {e}") from e
+    bad = [(r, e) for r, e in enumerate(err) if e is not None]
+    if bad:   # a rank that fails leaves its peers to time out in their next collective: report the root cause first
+        bad.sort(key=lambda re_: ("peer rank failed" in str(re_[1])) + 2 * ("timed out" in str(re_[1])))
+        raise AssertionError("; ".join(f"rank {r}: {type(e).__name__}: {str(e)[:300]}" for r, e in bad[:3])) from bad[0][1]
     return out
 
 
@@ -337,8 +338,8 @@ def test_library_rng_update_world2_replays_through_the_oracle(mode):
         draws = []
         orig = disc.update_gail_dyn
 
-        def spy(loader, rollouts):
-            out = orig(loader, rollouts)
+        def spy(loader, rollouts, **k):
+            out = orig(loader, rollouts, **k)
             draws.append(disc.last_draws())
             return out
         disc.update_gail_dyn = spy

@@ -1,34 +1,24 @@
 #!/bin/bash
 # Collects the per-round evidence on the GPU box into gpurun_out/ (copy what should be judged into profiles/):
-#   kernel trace (+gaps), FETCH_SIZE and WRITE_SIZE in separate --pmc passes, the bench line, the pytest tail.
+#   for EVERY workload of bench.py: kernel trace, FETCH_SIZE and WRITE_SIZE in separate --pmc passes, the bench line
+#   (tools/profile_workload.sh); the PMC calibration on known byte counts; the N > 1 self-test lines of bench.py
+#   (--gpus 2 / 8 over the loopback communicator); the pytest -m gpu tail; the end-to-end parity record.
 # Usage (from the repo root on the GPU box):  bash tools/profile_round.sh <tag>
+# Afterwards, in the dev container:  cp gpurun_out/<tag>_* profiles/ ; python tools/make_traffic.py <tag> <tag>
 set -u
 tag=${1:-rXX}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
-run_prof() {  # name, rocprofv3 args...
-    local name=$1; shift
-    rm -rf /tmp/prof_$name
-    timeout 600 rocprofv3 "$@" -d /tmp/prof_$name -o $name --output-format rocpd -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_${name}_bench_under_profiler.json 2> /tmp/prof_$name.err
-    find /tmp/prof_$name -name "*.db" | head -1
-}
-db=$(run_prof trace --kernel-trace)
-python $root/tools/rocpd_stats.py $db > $out/${tag}_kernel_trace.txt
-db=$(run_prof fetch --pmc FETCH_SIZE --kernel-trace)
-python $root/tools/rocpd_pmc.py $db > $out/${tag}_pmc_fetch_size.txt
-db=$(run_prof write --pmc WRITE_SIZE --kernel-trace)
-python $root/tools/rocpd_pmc.py $db > $out/${tag}_pmc_write_size.txt
 cd $root
-timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-for w in hopper laikago refine; do   # the other BASELINE.json configurations (DESIGN.md section 5 quotes these files)
-    timeout 600 python bench.py --workload $w --cpu-seconds 8 > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err
+for w in northstar hopper laikago refine; do
+    bash tools/profile_workload.sh $tag $w > $out/${tag}_${w}_profile.log 2>&1
 done
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_pytest_gpu.txt
-rm -f $out/${tag}_*_bench_under_profiler.json
+bash tools/profile_calibration.sh $tag 1024 > $out/${tag}_calibration.log 2>&1
+for n in 2 8; do
+    timeout 900 python bench.py --gpus $n --loopback --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_loopback_n$n.json 2> $out/${tag}_bench_loopback_n$n.err
+done
+SG_PARITY_RECORD=$out/${tag}_parity.json timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_pytest_gpu.txt
+rm -f $out/${tag}_*_profile.log $out/${tag}_calibration.log $out/${tag}_*.err
 tail -3 $out/${tag}_pytest_gpu.txt
-head -14 $out/${tag}_kernel_trace.txt
-head -8 $out/${tag}_pmc_fetch_size.txt
-head -8 $out/${tag}_pmc_write_size.txt
-cut -c1-300 $out/${tag}_bench.json
+for w in northstar hopper laikago refine; do head -9 $out/${tag}_${w}_kernel_trace.txt | tail -6; cut -c1-160 $out/${tag}_${w}_bench.json; done
