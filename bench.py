@@ -388,7 +388,7 @@ def main():
             "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()},
             "kernel_launches": {k: v[1] for k, v in prof.items()},
             "us_per_optimizer_step": round(1e3 * ms_per_step / (work["d_steps"] + work["ppo_steps"]), 2),
-            "last_losses": last,
+            "last_losses": dict(last),
             "device": name, "num_cu": num_cu,
             "per_rank_ms_per_step": [round(1e3 * x / args.steps, 3) for x in per_rank],
         }

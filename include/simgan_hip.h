@@ -160,6 +160,15 @@ int sg_ppo_set_lr(sg_ppo *a, float lr);
  * [ppo_epoch][T*N*world] ids in its numbering t*(N*world) + rank*N + n, the same array on every rank; each rank takes
  * the rows of every minibatch it owns (NULL: every rank permutes its own rows and gives T*N/num_mini_batch per step). */
 int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, int64_t n_perms, uint64_t seed, float out3[3]);
+/* out3 may be NULL (as for sg_disc_update_gail_dyn): the update is queued and the call returns without waiting for it.
+ * An outer iteration made of such calls -- sg_disc_update_gail_dyn x gail_epoch, sg_disc_relabel_rewards_auto,
+ * sg_rollout_compute_returns_policy, sg_ppo_update, sg_rollout_after_update -- never makes the host wait; its scalars (the
+ * reference main's log line, a2c/main_gail_dyn_ppo.py:322-338) are published into one of SG_RESULT_SLOTS = 8 pinned
+ * host slots by sg_results_publish (d and/or a may be NULL) and read with sg_results_fetch when the caller wants them:
+ * out13 = {D loss sums x3 of the last epoch, ret_rms mean / var / count, sum(1 - masks), r_sa, PPO loss sums x3,
+ * n_d, ppo_epoch * num_mini_batch}; losses = sums / their step count (float32, as the synchronous calls return them). */
+int sg_results_publish(sg_ctx *ctx, sg_disc *d, sg_ppo *a, int slot);
+int sg_results_fetch(sg_ctx *ctx, int slot, double out13[13]);
 /* Adam state access for checkpoint/parity: m, v flat [n] in state_dict order; *step = t. */
 /* The permutations the last sg_ppo_update consumed ([ppo_epoch][T*N], injected or library-drawn), so a run made
  * with the library's generator can be replayed elsewhere (the role torch.manual_seed plays for the reference). */
@@ -226,6 +235,13 @@ int sg_disc_set_returns(sg_disc *d, const float *returns, int n);
  * updated in place.  Writes rollout field REWARDS. */
 int sg_disc_relabel_rewards(sg_disc *d, sg_rollout *r, float gamma, float offset,
                             double rms_state[3]);
+/* The same with the alive-bonus offset computed on the device as well (a2c/main_gail_dyn_ppo.py:258-271: r_sa from
+ * sum(1 - masks), num_processes (all ranks), num_steps and gail_tar_length; no_alive_bonus != 0 -> 0) and ret_rms kept inside
+ * the handle (initially RunningMeanStd(): {0, 1, 1e-4}): nothing is read back, the call only queues work.
+ * sg_disc_set_rms overwrites the resident state; sg_disc_get_scalars reads {mean, var, count, sum(1 - masks), r_sa}. */
+int sg_disc_relabel_rewards_auto(sg_disc *d, sg_rollout *r, float gamma, double gail_tar_length, int no_alive_bonus);
+int sg_disc_set_rms(sg_disc *d, const double rms_state[3]);
+int sg_disc_get_scalars(sg_disc *d, double out5[5]);
 /* sum(1 - masks) over all T+1 slots (a2c/main_gail_dyn_ppo.py:258), for the alive-bonus offset. */
 int sg_rollout_count_dones(sg_rollout *r, double *dones);
 

@@ -94,6 +94,11 @@ PROTOTYPES = {
     "sg_disc_get_returns": (C.c_int, [H, c_float_p, C.c_int, c_int_p]),
     "sg_disc_set_returns": (C.c_int, [H, c_float_p, C.c_int]),
     "sg_disc_relabel_rewards": (C.c_int, [H, H, C.c_float, C.c_float, c_double_p]),
+    "sg_disc_relabel_rewards_auto": (C.c_int, [H, H, C.c_float, C.c_double, C.c_int]),
+    "sg_disc_set_rms": (C.c_int, [H, c_double_p]),
+    "sg_disc_get_scalars": (C.c_int, [H, c_double_p]),
+    "sg_results_publish": (C.c_int, [H, H, H, C.c_int]),
+    "sg_results_fetch": (C.c_int, [H, C.c_int, c_double_p]),
     "sg_ctx_profile": (C.c_int, [H, C.c_int]),
     "sg_ctx_profile_read": (C.c_int, [H, C.c_int, c_double_p, c_i64_p]),
     "sg_ctx_profile_reset": (C.c_int, [H]),

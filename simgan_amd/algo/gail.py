@@ -260,6 +260,25 @@ class Discriminator(object):
             _lib.check(self.lib.sg_disc_set_returns(self.h, _lib.fptr(v), v.size))
             self._ret_n = v.size
 
+    def relabel_rewards_auto(self, rollouts, gamma, gail_tar_length, no_alive_bonus=False):
+        """a2c/main_gail_dyn_ppo.py:258-297 entirely on the device, nothing read back: the alive-bonus offset from the
+        device's own done count, the fused relabel, ret_rms kept inside the library (`set_rms` / `scalars`).  Device-resident
+        rollouts only (the rewards stay in HBM)."""
+        assert rollouts.device_resident, "relabel_rewards_auto leaves the rewards on the device"
+        _lib.check(self.lib.sg_disc_relabel_rewards_auto(self.h, rollouts.h, float(gamma), float(gail_tar_length),
+                                                         1 if no_alive_bonus else 0))
+        self._ret_n = rollouts.num_processes
+
+    def set_rms(self, state):
+        st = (C.c_double * 3)(*[float(x) for x in state])
+        _lib.check(self.lib.sg_disc_set_rms(self.h, st))
+
+    def scalars(self):
+        """{mean, var, count} of the device-resident ret_rms, sum(1 - masks) and r_sa of the last relabel_rewards_auto."""
+        out = (C.c_double * 5)()
+        _lib.check(self.lib.sg_disc_get_scalars(self.h, out))
+        return list(out)
+
     def relabel_rewards(self, rollouts, gamma, offset, ret_rms):
         """Fused a2c/main_gail_dyn_ppo.py:275-292 over all T steps on device; ret_rms is the caller's
         RunningMeanStd (float64 state updated in place); rollouts.rewards is rewritten."""

@@ -87,21 +87,23 @@ class PPO():
         except Exception:
             pass
 
-    def update(self, rollouts, perms=None):
+    def update(self, rollouts, perms=None, fetch_losses=True):
         """a2c/algo/ppo.py:65-157 -> (value_loss_epoch, action_loss_epoch, dist_entropy_epoch).
         `perms` ([ppo_epoch, T*N] int64) injects the samplers' permutations (parity tests);
         default = the library's counter-based generator.  With a communicator of world > 1 the injected
         permutations are the reference's at num_processes = world * N: [ppo_epoch, T*N*world], the same on every rank
-        (include/simgan_hip.h: sg_ppo_update)."""
+        (include/simgan_hip.h: sg_ppo_update).  fetch_losses=False: queue the update and return None without waiting for
+        it (the losses are read later through the results ring, simgan_amd/driver.py)."""
         rollouts._push([_lib.F_OBS, _lib.F_ACTIONS, _lib.F_VALUE_PREDS, _lib.F_RETURNS, _lib.F_LOGP])
         out = (C.c_float * 3)()
         self._calls += 1
         if perms is not None:
             perms = _lib.as_i64(perms).reshape(self.ppo_epoch, -1)   # lengths and index ranges are checked behind the C ABI
         _lib.check(self.lib.sg_ppo_update(self.h, rollouts.h, None if perms is None else _lib.i64ptr(perms),
-                                          0 if perms is None else perms.size, (self.seed + self._calls) & (2 ** 64 - 1), out))
+                                          0 if perms is None else perms.size, (self.seed + self._calls) & (2 ** 64 - 1),
+                                          out if fetch_losses else None))
         self._last_perm_shape = (self.ppo_epoch, rollouts.num_steps * rollouts.num_processes)
-        return float(out[0]), float(out[1]), float(out[2])
+        return (float(out[0]), float(out[1]), float(out[2])) if fetch_losses else None
 
     def last_perms(self):
         """[ppo_epoch, T*N] permutations the last update() consumed (injected or library-drawn)."""

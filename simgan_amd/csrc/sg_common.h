@@ -112,7 +112,13 @@ struct sg_ctx {
     void* h_pinned = nullptr;     // pinned host staging
     size_t pinned_bytes = 0;
     double* mailbox = nullptr;    // 2 x 64 doubles of device-visible pinned host memory: small results / small inputs
+    // results ring: SG_RESULT_SLOTS x 16 doubles of device-visible pinned host memory.  An update that runs without a host
+    // synchronisation publishes its scalars (losses, r_sa, ret_rms) into a slot with a one-wave kernel and records the slot's
+    // event; the host reads the slot when it wants the numbers (sg_results_publish / sg_results_fetch).
+    double* results = nullptr;
+    hipEvent_t res_ev[8] = {nullptr};
 };
+#define SG_RESULT_SLOTS 8
 
 int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out);
 int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out);
@@ -207,6 +213,8 @@ struct sg_disc {
     float* d_rows = nullptr;       // sg_disc_update_rows: caller-assembled policy rows
     int64_t rows_cap = 0;
     double* d_loss_acc = nullptr;
+    double* d_scal = nullptr;      // device-resident learner scalars: ret_rms {mean, var, count} | sum(1 - masks) | r_sa
+    int last_n_d = 0;              // steps of the last epoch (its loss sums in d_loss_acc are divided by this)
     float* d_returns = nullptr;    // Discriminator.returns [n]
     int returns_n = 0;
     bool returns_none = true;
@@ -284,6 +292,8 @@ static inline int sg_try_capture(sg_ctx* ctx, hipGraphExec_t* exec, F&& enqueue)
 // collectives (sg_comm.cpp): RCCL, or the one-host loopback transport
 int sg_comm_graph_ok(const sg_ctx* ctx);   // 1: the collectives are stream operations that a hipGraph capture records
 void sg_comm_destroy(sg_ctx* ctx);
+// sum(1 - masks) over the rollout's T+1 slots (all ranks) into a device double, no host synchronisation (sg_rollout.hip)
+int sg_rollout_count_dones_dev(sg_rollout* r, double* d_out);
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n);
 int sg_comm_allreduce_f64(sg_ctx* ctx, double* dev, int64_t n);
 int sg_comm_allgather_f32(sg_ctx* ctx, const float* dev_in, float* dev_out, int64_t n_per_rank);

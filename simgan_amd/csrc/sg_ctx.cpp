@@ -42,6 +42,8 @@ extern "C" int sg_ctx_create(int device, sg_ctx** out) {
                "sg_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     SG_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SG_CHECK(hipHostMalloc((void**)&ctx->mailbox, sizeof(double) * 128, hipHostMallocDefault));
+    SG_CHECK(hipHostMalloc((void**)&ctx->results, sizeof(double) * 16 * SG_RESULT_SLOTS, hipHostMallocDefault));
+    for (int i = 0; i < SG_RESULT_SLOTS; ++i) SG_CHECK(hipEventCreateWithFlags(&ctx->res_ev[i], hipEventDisableTiming));
     *out = ctx;
     return 0;
 }
@@ -57,6 +59,8 @@ extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->results) (void)hipHostFree(ctx->results);
+    for (auto e : ctx->res_ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

@@ -88,6 +88,7 @@ struct DiscFwdArgs {
     const float* x;   // [n, F]
     int n;
     float offset;
+    const double* neg_offset_dev;   // != NULL: offset = -(float)*neg_offset_dev (the alive-bonus r_sa computed on the device)
     float* reward;    // [n]  log(s+1e-7) - log(1-s+1e-7) + offset   (prob != 0: sigmoid(D(x)), a2c/algo/gail.py:212-217)
     int prob;
 };
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
     const float* b2 = W + d.b2;
     const float* w3 = W + d.w3;
     sg_stage(W, a.params, d.total / 4);
+    const float offset = a.neg_offset_dev ? -(float)(*a.neg_offset_dev) : a.offset;
     for (int base = blockIdx.x * R; base < a.n; base += gridDim.x * R) {
         __syncthreads();
         {   // the row tile through range-checked buffer loads, all requests of a thread in flight together: rows past
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
         if (sub == 0 && base + r < a.n) {
             const float sg = sg_sigmoid(s + W[d.b3]);
-            a.reward[base + r] = a.prob ? sg : logf(sg + 1e-7f) - logf(1.f - sg + 1e-7f) + a.offset;  // a2c/algo/gail.py:204-205
+            a.reward[base + r] = a.prob ? sg : logf(sg + 1e-7f) - logf(1.f - sg + 1e-7f) + offset;  // a2c/algo/gail.py:204-205
         }
     }
 }
@@ -246,6 +248,12 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_state, sizeof(SgOptState)));
     SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
+    SG_CHECK(hipMalloc((void**)&d->d_scal, sizeof(double) * 8));
+    {
+        const double scal0[8] = {0.0, 1.0, 1e-4, 0.0, 0.0, 0.0, 0.0, 0.0};   // RunningMeanStd(): mean 0, var 1, count 1e-4
+        SG_CHECK(hipMemcpyAsync(d->d_scal, scal0, sizeof scal0, hipMemcpyHostToDevice, ctx->stream));
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     const size_t wT_f = (size_t)2 * d->desc.Hp * (d->desc.Fp + d->desc.Hp);   // images of W1, W2, W2^T, W1^T
     SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * wT_f));
     SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * wT_f, ctx->stream));
@@ -269,6 +277,7 @@ extern "C" int sg_disc_destroy(sg_disc* d) {
     if (d->d_eperm) (void)hipFree(d->d_eperm);
     if (d->d_pperm) (void)hipFree(d->d_pperm);
     if (d->d_loss_acc) (void)hipFree(d->d_loss_acc);
+    if (d->d_scal) (void)hipFree(d->d_scal);
     if (d->epoch_graph) (void)hipGraphExecDestroy(d->epoch_graph);
     delete d;
     return 0;
@@ -602,6 +611,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     SG_CHECK(hipGetLastError());
     const auto t_enq1 = std::chrono::steady_clock::now();
     d->opt_t += n_d;
+    d->last_n_d = n_d;
     // out3 == NULL: the caller does not want this epoch's losses (the reference's main keeps only the last epoch's,
     // a2c/main_gail_dyn_ppo.py:255-256) -- the epoch stays queued, the host does not wait for it, and the next epoch's launch
     // overlaps its execution.  Everything the next call touches is ordered behind it on the library's stream.
@@ -640,10 +650,12 @@ extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t
                             n_alpha, seed, out3, n_steps);
 }
 
-static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward, int prob = 0) {
+static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, float* d_reward, int prob = 0,
+                            const double* neg_offset_dev = nullptr) {
     sg_ctx* ctx = d->ctx;
     DiscFwdArgs f;
     f.d = d->desc; f.params = d->d_params; f.x = d_x; f.n = n; f.offset = offset; f.reward = d_reward; f.prob = prob;
+    f.neg_offset_dev = neg_offset_dev;
     int grid = (n + 31) / 32;
     if (grid > 2 * ctx->num_cu) grid = 2 * ctx->num_cu;
     SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), f);
@@ -740,8 +752,8 @@ extern "C" int sg_disc_set_returns(sg_disc* d, const float* returns, int n) {
     return 0;
 }
 
-extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, float offset, double rms_state[3]) {
-    SG_REQUIRE(d && r && rms_state, "sg_disc_relabel_rewards: NULL argument");
+// rms_dev: device {mean, var, count}, updated in place; neg_offset_dev != NULL: the offset is -(*neg_offset_dev)
+static int relabel_core(sg_disc* d, sg_rollout* r, float gamma, float offset, const double* neg_offset_dev, double* rms_host) {
     sg_ctx* ctx = d->ctx;
     SG_REQUIRE(r->F == d->desc.F, "sg_disc_relabel_rewards: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
     SG_CHECK(hipSetDevice(ctx->device));
@@ -754,12 +766,12 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     SG_TRY(sg_ctx_scratch(ctx, bytes, &scratch));
     float* rets = scratch;
     double* stats = reinterpret_cast<double*>(scratch + ((TN + 3) & ~(int64_t)3));
-    double* rms = stats + 2 * (size_t)T;
-    float* scale = reinterpret_cast<float*>(rms + 4);
-    SG_TRY(sg_ctx_put_f64(ctx, rms, rms_state, 3));
+    double* rms = rms_host ? stats + 2 * (size_t)T : d->d_scal;   // caller's state staged in scratch, or the device-resident one
+    float* scale = reinterpret_cast<float*>(stats + 2 * (size_t)T + 4);
+    if (rms_host) SG_TRY(sg_ctx_put_f64(ctx, rms, rms_host, 3));
     float* rewards = r->d_field[SG_F_REWARDS];
     // rewards[t] <- D(obs_feat[t+1]) (+offset): rows t*N+n of obs_feat[1:]
-    SG_TRY(disc_forward_dev(d, r->d_field[SG_F_OBS_FEAT] + (size_t)N * r->F, (int)TN, offset, rewards));
+    SG_TRY(disc_forward_dev(d, r->d_field[SG_F_OBS_FEAT] + (size_t)N * r->F, (int)TN, offset, rewards, 0, neg_offset_dev));
     hipLaunchKernelGGL(k_returns_scan, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, d->d_returns, rewards,
                        r->d_field[SG_F_MASKS], gamma, d->returns_none ? 1 : 0, T, N, rets);
     d->returns_none = false;
@@ -771,7 +783,43 @@ extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, f
     hipLaunchKernelGGL(k_rms_scan, dim3(1), dim3(256), sizeof(double) * 3 * T, ctx->stream, stats, T, n_global, rms, scale);
     hipLaunchKernelGGL(k_normalize_rewards, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, ctx->stream, rewards, scale, T, N);
     SG_CHECK(hipGetLastError());
-    SG_TRY(sg_ctx_fetch_f64(ctx, rms, rms_state, 3));
+    if (rms_host) SG_TRY(sg_ctx_fetch_f64(ctx, rms, rms_host, 3));
+    return 0;
+}
+
+extern "C" int sg_disc_relabel_rewards(sg_disc* d, sg_rollout* r, float gamma, float offset, double rms_state[3]) {
+    SG_REQUIRE(d && r && rms_state, "sg_disc_relabel_rewards: NULL argument");
+    return relabel_core(d, r, gamma, offset, nullptr, rms_state);
+}
+
+// a2c/main_gail_dyn_ppo.py:258-271 on the device: dones = sum(1 - masks) + N/2; d = 1 - dones / (dones + T*N/len_e);
+// r_sa = log d - log(1 - d)   (float64, as numpy computes it on the host)
+__global__ void k_alive_bonus(double* scal, double n_glob, double t_steps, double tar_length, int no_alive_bonus) {
+    const double dones = scal[3] + n_glob / 2.0;
+    const double expert_dones = (t_steps * n_glob) / tar_length;
+    const double d_sa = 1.0 - dones / (dones + expert_dones);
+    scal[4] = no_alive_bonus ? 0.0 : log(d_sa) - log(1.0 - d_sa);
+}
+
+extern "C" int sg_disc_relabel_rewards_auto(sg_disc* d, sg_rollout* r, float gamma, double gail_tar_length, int no_alive_bonus) {
+    SG_REQUIRE(d && r && gail_tar_length > 0, "sg_disc_relabel_rewards_auto: bad argument");
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    SG_TRY(sg_rollout_count_dones_dev(r, d->d_scal + 3));
+    hipLaunchKernelGGL(k_alive_bonus, dim3(1), dim3(1), 0, ctx->stream, d->d_scal, (double)r->N * ctx->world, (double)r->T,
+                       gail_tar_length, no_alive_bonus);
+    return relabel_core(d, r, gamma, 0.f, d->d_scal + 4, nullptr);
+}
+
+extern "C" int sg_disc_set_rms(sg_disc* d, const double rms_state[3]) {
+    SG_REQUIRE(d && rms_state, "sg_disc_set_rms: NULL argument");
+    SG_COPY_SYNC(d->ctx, d->d_scal, rms_state, sizeof(double) * 3, hipMemcpyHostToDevice);
+    return 0;
+}
+
+extern "C" int sg_disc_get_scalars(sg_disc* d, double out5[5]) {
+    SG_REQUIRE(d && out5, "sg_disc_get_scalars: NULL argument");
+    SG_COPY_SYNC(d->ctx, out5, d->d_scal, sizeof(double) * 5, hipMemcpyDeviceToHost);
     return 0;
 }
 

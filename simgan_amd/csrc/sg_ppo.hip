@@ -149,12 +149,14 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     return 0;
 }
 
+__global__ void k_set_lr(SgOptState* st, float lr) { st->lr = lr; }
+
 extern "C" int sg_ppo_set_lr(sg_ppo* a, float lr) {
     SG_REQUIRE(a, "sg_ppo_set_lr: NULL argument");
     a->cfg.lr = lr;
-    SG_CHECK(hipMemcpyAsync(&reinterpret_cast<SgOptState*>(a->d_state)->lr, &a->cfg.lr, sizeof(float),
-                            hipMemcpyHostToDevice, a->ctx->stream));
-    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    // by kernel argument, in stream order: no host synchronisation (the schedule writes it before every update)
+    hipLaunchKernelGGL(k_set_lr, dim3(1), dim3(1), 0, a->ctx->stream, reinterpret_cast<SgOptState*>(a->d_state), lr);
+    SG_CHECK(hipGetLastError());
     return 0;
 }
 
@@ -201,7 +203,7 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
 }
 
 extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int64_t n_perms, uint64_t seed, float out3[3]) {
-    SG_REQUIRE(a && r && out3, "sg_ppo_update: NULL argument");
+    SG_REQUIRE(a && r, "sg_ppo_update: NULL argument");
     sg_ctx* ctx = a->ctx;
     const SgPolicyDesc& d = a->policy->desc;
     SG_REQUIRE(r->O == d.O && r->A == d.A, "sg_ppo_update: rollout dims (obs %d, act %d) do not match the policy (%d, %d)",
@@ -427,11 +429,44 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     }
     if (!use_graph) SG_TRY(enqueue_steps());
     SG_CHECK(hipGetLastError());
+    a->opt_t += (int64_t)E * M;
+    if (!out3) return 0;   // the caller reads the losses later (sg_results_publish): the update stays queued, no host wait
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
     const double nu = (double)E * M;
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
-    a->opt_t += (int64_t)E * M;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- results ring
+// One update's scalars, published without a host synchronisation: slot layout (doubles)
+//   [0..2] discriminator loss sums of the last epoch (divide by [11])   [3..5] ret_rms mean / var / count   [6] sum(1 - masks)
+//   [7] r_sa   [8..10] PPO loss sums (divide by [12])   [11] n_d   [12] ppo_epoch * num_mini_batch
+__global__ void k_publish(double* dst, const double* d_acc, const double* d_scal, const double* p_acc, double n_d, double n_p) {
+    const int t = threadIdx.x;
+    if (t < 3) dst[t] = d_acc ? d_acc[t] : 0.0;
+    else if (t < 8) dst[t] = d_scal ? d_scal[t - 3] : 0.0;
+    else if (t < 11) dst[t] = p_acc ? p_acc[t - 8] : 0.0;
+    else if (t == 11) dst[t] = n_d;
+    else if (t == 12) dst[t] = n_p;
+}
+
+extern "C" int sg_results_publish(sg_ctx* ctx, sg_disc* d, sg_ppo* a, int slot) {
+    SG_REQUIRE(ctx && slot >= 0 && slot < SG_RESULT_SLOTS, "sg_results_publish: bad argument");
+    SG_REQUIRE((!d || d->ctx == ctx) && (!a || a->ctx == ctx), "sg_results_publish: objects of another context");
+    SG_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->results + 16 * slot, d ? d->d_loss_acc : nullptr,
+                       d ? d->d_scal : nullptr, a ? a->d_loss_acc : nullptr, d ? (double)d->last_n_d : 1.0,
+                       a ? (double)a->cfg.ppo_epoch * a->cfg.num_mini_batch : 1.0);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_results_fetch(sg_ctx* ctx, int slot, double out13[13]) {
+    SG_REQUIRE(ctx && out13 && slot >= 0 && slot < SG_RESULT_SLOTS, "sg_results_fetch: bad argument");
+    SG_CHECK(hipEventSynchronize(ctx->res_ev[slot]));
+    memcpy(out13, ctx->results + 16 * slot, sizeof(double) * 13);
     return 0;
 }
 

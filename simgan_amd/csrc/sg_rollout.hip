@@ -219,6 +219,14 @@ __global__ void k_count_dones(const float* masks, int64_t n, double* out) {
     }
 }
 
+int sg_rollout_count_dones_dev(sg_rollout* r, double* d_out) {
+    hipLaunchKernelGGL(k_count_dones, dim3(1), dim3(1024), 0, r->ctx->stream, r->d_field[SG_F_MASKS],
+                       (int64_t)(r->T + 1) * r->N, d_out);
+    SG_CHECK(hipGetLastError());
+    if (r->ctx->use_comm) SG_TRY(sg_comm_allreduce_f64(r->ctx, d_out, 1));
+    return 0;
+}
+
 extern "C" int sg_rollout_count_dones(sg_rollout* r, double* dones) {
     SG_REQUIRE(r && dones, "sg_rollout_count_dones: NULL argument");
     float* scratch = nullptr;

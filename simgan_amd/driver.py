@@ -13,12 +13,65 @@ torch.load, gym/pybullet), so this module reproduces their per-iteration call se
 `step(action) -> (obs, reward, done, infos)` with `info["sas_feat"]` rows (the reference builds them
 from info["sas_window"], a2c/main_gail_dyn_ppo.py:220-226).
 """
+import collections.abc
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
 from .utils import RunningMeanStd, to_host_tensor, update_linear_schedule
+
+_RESULT_SLOTS = 8
+
+
+class PendingLosses(collections.abc.Mapping):
+    """What `update()` returns on a device-resident rollout: the update's scalars (the reference main's log line,
+    a2c/main_gail_dyn_ppo.py:322-338) as a read-only mapping that is filled from the library's results ring on first access.
+    The update itself never makes the host wait, so the next update is queued while this one runs; a caller that logs every
+    `log_interval` updates only pays for the ones it reads.  `resolve()` returns a plain dict."""
+
+    def __init__(self, ctx, slot, keys):
+        self._ctx, self._slot, self._keys, self._vals = ctx, slot, keys, None
+
+    def resolve(self):
+        if self._vals is None:
+            out = (C.c_double * 13)()
+            _lib.check(self._ctx.lib.sg_results_fetch(self._ctx.h, self._slot, out))
+            f32 = lambda x: float(np.float32(x))  # noqa: E731  (loss.item() values are float32 in the reference)
+            vals = {"gail_loss": f32(out[0] / out[11]), "gail_loss_e": f32(out[1] / out[11]), "gail_loss_p": f32(out[2] / out[11]),
+                    "value_loss": f32(out[8] / out[12]), "action_loss": f32(out[9] / out[12]), "dist_entropy": f32(out[10] / out[12]),
+                    "r_sa": float(out[7]), "ret_rms": [float(out[3]), float(out[4]), float(out[5])], "dones": float(out[6])}
+            self._vals = {k: vals[k] for k in self._keys}
+        return self._vals
+
+    def __getitem__(self, k):
+        return self.resolve()[k]
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __repr__(self):
+        return f"PendingLosses({self._vals if self._vals is not None else 'not read yet'})"
+
+
+class _ResultRing(object):
+    """Slots of the library's results ring, handed out round-robin; a slot is read (so its mapping keeps its numbers)
+    before it is published into again."""
+
+    def __init__(self, ctx):
+        self.ctx, self.n, self.live = ctx, 0, [None] * _RESULT_SLOTS
+
+    def publish(self, disc, agent, keys):
+        slot = self.n % _RESULT_SLOTS
+        self.n += 1
+        if self.live[slot] is not None:
+            self.live[slot].resolve()
+        _lib.check(self.ctx.lib.sg_results_publish(self.ctx.h, disc.h if disc is not None else None, agent.h, slot))
+        self.live[slot] = PendingLosses(self.ctx, slot, keys)
+        return self.live[slot]
 
 
 def alive_bonus_offset(num_of_dones, num_steps, num_processes, gail_tar_length, no_alive_bonus=False):
@@ -52,9 +105,23 @@ class GailDynLearner(object):
         self.use_gae, self.use_proper_time_limits = use_gae, use_proper_time_limits
         self.gail_tar_length, self.no_alive_bonus = gail_tar_length, no_alive_bonus
         self.use_linear_lr_decay, self.lr, self.num_updates = use_linear_lr_decay, lr, num_updates
-        self.ret_rms = RunningMeanStd(shape=())        # a2c/main_gail_dyn_ppo.py:198-199
+        self._ret_rms = RunningMeanStd(shape=())       # a2c/main_gail_dyn_ppo.py:198-199
+        self._rms_on_device = False                    # the state lives in the library while updates run device-resident
         self.j = 0
         self.world = getattr(rollouts.ctx, "world", 1)
+        self._ring = _ResultRing(rollouts.ctx)
+
+    @property
+    def ret_rms(self):
+        if self._rms_on_device:
+            self._ret_rms.set_state(self.discr.scalars()[:3])
+        return self._ret_rms
+
+    @ret_rms.setter
+    def ret_rms(self, value):
+        self._ret_rms = value
+        if self._rms_on_device:
+            self.discr.set_rms(value.get_state())
 
     # ---------------------------------------------------------------- rollout fill (:209-236)
     def collect(self, envs, sas_feat_of_infos):
@@ -74,32 +141,53 @@ class GailDynLearner(object):
         ro, lib = self.rollouts, self.rollouts.lib
         if self.use_linear_lr_decay:            # :203-207
             update_linear_schedule(self.agent.optimizer, self.j, self.num_updates, self.lr)
+        if ro.device_resident:
+            return self._update_resident()
+        if self._rms_on_device:                 # a drop-in update after device-resident ones: bring the state back
+            self._ret_rms.set_state(self.discr.scalars()[:3])
+            self._rms_on_device = False
         gail = None
         for e in range(self.gail_epoch):        # :255-256 -- the reference keeps the last epoch's losses only
             last = e == self.gail_epoch - 1
             gail = self.discr.update_gail_dyn(self.loader, ro, **({} if last else {"fetch_losses": False}))
-        if ro.device_resident:
-            dones = C.c_double(0)
-            _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))   # all ranks (RCCL) when world > 1
-            n_dones = dones.value
-        else:
-            m = ro.masks.numpy() if hasattr(ro.masks, "numpy") else ro.masks
-            n_dones = float((1.0 - m).sum())
-        r_sa = alive_bonus_offset(n_dones, ro.num_steps, ro.num_processes * self.world, self.gail_tar_length,
+        # drop-in mode: the host tensors are the rollout; every call below uploads what it reads and returns its result
+        ro.sync_to_device([_lib.F_MASKS])
+        dones = C.c_double(0)
+        _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))   # all ranks when world > 1
+        r_sa = alive_bonus_offset(dones.value, ro.num_steps, ro.num_processes * self.world, self.gail_tar_length,
                                   self.no_alive_bonus)
-        self.discr.relabel_rewards(ro, self.gamma, -r_sa, self.ret_rms)     # :275-297 fused on device
-        if ro.device_resident:
-            _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, self.actor_critic.h, 1 if self.use_gae else 0,
-                                                             float(self.gamma), float(self.gae_lambda),
-                                                             1 if self.use_proper_time_limits else 0))
-        else:
-            next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
-            ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
+        self.discr.relabel_rewards(ro, self.gamma, -r_sa, self._ret_rms)    # :275-297 fused on device
+        next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
+        ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
         ppo = self.agent.update(ro)             # :302
         ro.after_update()                       # :304
         self.j += 1
         return {"gail_loss": gail[0], "gail_loss_e": gail[1], "gail_loss_p": gail[2], "value_loss": ppo[0],
                 "action_loss": ppo[1], "dist_entropy": ppo[2], "r_sa": r_sa}
+
+
+def _gail_update_resident(self):
+    """GailDynLearner.update() on a device-resident rollout: the same call sequence, every call only QUEUES work on the
+    library's stream -- discriminator epochs without their loss read-back, the alive-bonus offset from the device's done
+    count, ret_rms resident in the library, GAE with get_value(obs[T]) on the device, PPO, after_update -- and the scalars
+    are published into the results ring at the end.  The host never waits inside an update."""
+    ro, lib = self.rollouts, self.rollouts.lib
+    if not self._rms_on_device:
+        self.discr.set_rms(self._ret_rms.get_state())
+        self._rms_on_device = True
+    for _ in range(self.gail_epoch):            # :255-256
+        self.discr.update_gail_dyn(self.loader, ro, fetch_losses=False)
+    self.discr.relabel_rewards_auto(ro, self.gamma, self.gail_tar_length, self.no_alive_bonus)     # :258-297
+    _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, self.actor_critic.h, 1 if self.use_gae else 0, float(self.gamma),
+                                                     float(self.gae_lambda), 1 if self.use_proper_time_limits else 0))
+    self.agent.update(ro, fetch_losses=False)   # :302
+    ro.after_update()                           # :304
+    self.j += 1
+    return self._ring.publish(self.discr, self.agent, ("gail_loss", "gail_loss_e", "gail_loss_p", "value_loss", "action_loss",
+                                                       "dist_entropy", "r_sa"))
+
+
+GailDynLearner._update_resident = _gail_update_resident
 
 
 class PpoLearner(object):
@@ -121,6 +209,7 @@ class PpoLearner(object):
         if use_linear_lr_decay:
             assert lr is not None and num_updates, "linear LR decay needs the initial lr and num_updates (a2c/main.py:196-205)"
         self.j = 0
+        self._ring = _ResultRing(rollouts.ctx)
 
     @staticmethod
     def warm_start(path, obs_shape, action_space, warm_start_logstd=None, ctx=None, critic_seed=1):
@@ -151,13 +240,16 @@ class PpoLearner(object):
         ro, lib = self.rollouts, self.rollouts.lib
         if self.use_linear_lr_decay:
             update_linear_schedule(self.agent.optimizer, self.j, self.num_updates, self.lr)
-        if ro.device_resident:
+        if ro.device_resident:   # nothing below waits for the device: the losses are read from the results ring on demand
             _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, self.actor_critic.h, 1 if self.use_gae else 0,
                                                              float(self.gamma), float(self.gae_lambda),
                                                              1 if self.use_proper_time_limits else 0))
-        else:
-            next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
-            ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
+            self.agent.update(ro, fetch_losses=False)
+            ro.after_update()
+            self.j += 1
+            return self._ring.publish(None, self.agent, ("value_loss", "action_loss", "dist_entropy"))
+        next_value = self.actor_critic.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1])
+        ro.compute_returns(next_value, self.use_gae, self.gamma, self.gae_lambda, self.use_proper_time_limits)
         value_loss, action_loss, dist_entropy = self.agent.update(ro)
         ro.after_update()
         self.j += 1

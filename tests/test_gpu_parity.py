@@ -673,7 +673,11 @@ def test_collect_then_update_device_resident_equals_drop_in(sg):
         results.append((outs, pol.get_flat_params(), disc.get_flat_params(), ro.obs.numpy()[0].copy(), ro.masks.numpy()[0].copy()))
     (o0, p0, d0, s0, m0), (o1, p1, d1, s1, m1) = results
     for a_, b_ in zip(o0, o1):
-        assert a_ == b_, (a_, b_)               # same kernels on the same data: bit-identical
+        # same kernels on the same data: bit-identical.  (The one host-computed scalar, r_sa, comes from numpy's float64 log in
+        # drop-in mode and from the device's in resident mode: equal to the last bit or two.)
+        a_, b_ = dict(a_), dict(b_)
+        assert a_.keys() == b_.keys() and a_.pop("r_sa") == pytest.approx(b_.pop("r_sa"), rel=1e-14)
+        assert a_ == b_, (a_, b_)
     assert np.array_equal(p0, p1) and np.array_equal(d0, d1) and np.array_equal(s0, s1) and np.array_equal(m0, m1)
     assert np.array_equal(s1, script[1][T - 1][0])
 

@@ -343,7 +343,7 @@ def test_library_rng_update_world2_replays_through_the_oracle(mode):
             draws.append(disc.last_draws())
             return out
         disc.update_gail_dyn = spy
-        info = learner.update()
+        info = dict(learner.update())           # read the results ring inside the rank's own thread
         ro.sync_from_device()
         return dict(info=info, draws=draws, perms=agent.last_perms(), pi=pol.get_flat_params(), dpar=disc.get_flat_params(),
                     rewards=ro.rewards.numpy()[..., 0].copy(), returns=ro.returns.numpy()[..., 0].copy(), rms=learner.ret_rms.get_state())

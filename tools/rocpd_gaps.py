@@ -21,7 +21,7 @@ def main(path):
     print(f"# inter-kernel gaps (ns) of {path}: end of previous dispatch -> start of next")
     print(f"{'previous':30s} {'next':30s} {'count':>7s} {'avg_ns':>9s} {'p50_ns':>9s} {'min_ns':>9s} {'total_ms':>9s}")
     for key, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
-        if len(v) < 5:
+        if len(v) < 3:
             continue
         v = sorted(v)
         print(f"{key[0]:30s} {key[1]:30s} {len(v):7d} {sum(v) / len(v):9.0f} {v[len(v) // 2]:9d} {v[0]:9d} {sum(v) / 1e6:9.3f}")
