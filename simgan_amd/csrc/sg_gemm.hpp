@@ -353,18 +353,22 @@ __device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, i
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < NTN; ++j) acc[j] = sg_mfma(a[src][c][s], b[src][c][s][j], acc[j]);
+                for (int j = 0; j < NTN; ++j) acc[j] = sg_mfma(b[src][c][s][j], a[src][c][s], acc[j]);
+    // The operands are SWAPPED (the products commute, the sums and their order are the same): the matrix core then leaves
+    // the tile transposed in the accumulators -- lane (li, lq) holds G[li][16 j + 4 lq .. + 3], four consecutive floats of one
+    // row -- so a tile goes out as one 16-byte store per lane (16 row segments of 64 bytes per instruction) instead of four
+    // 4-byte stores.  Round 3: the weight-gradient phases of k_ppo_bwd were bound by the issue of their dword stores.
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    typedef float sg_f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int j = 0; j < NTN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* p = G + (4 * lq + r) * ldg + 16 * j + li;
-            // a fresh gradient panel is written once and read by a later kernel: a streaming store lets it drain
-            // to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back
-            if (accumulate) *p = *p + acc[j][r];
-            else __builtin_nontemporal_store(acc[j][r], p);
-        }
+    for (int j = 0; j < NTN; ++j) {
+        sg_f4* p = reinterpret_cast<sg_f4*>(G + li * ldg + 16 * j + 4 * lq);
+        sg_f4 v = sg_f4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        // a fresh gradient panel is written once and read by a later kernel: a streaming store lets it drain
+        // to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back
+        if (accumulate) *p = *p + v;
+        else __builtin_nontemporal_store(v, p);
+    }
 }
 
 // NW_HINT: the number of waves the caller launches with when that is more than 4 (a compile-time hint, so that with

@@ -87,6 +87,14 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
     else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<2, 0, 0>), grid, block, lds, pa);
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
 }
+static void launch_ppo_fwd_critic(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
+    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const dim3 block(ppo_block_threads(MT));
+    if (MT == 2 && ko == 4 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 4, 7>), grid, block, lds, pa); return; }   // LaikagoCombined
+    if (MT == 2 && ko == 1 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 1, 7>), grid, block, lds, pa); return; }   // HopperCombined
+    if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<1, 0, 0>), grid, block, lds, pa);
+}
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(ppo_block_threads(MT));
@@ -304,7 +312,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const int G = (mb + R - 1) / R;
     const int mbp = G * R;
     const int ldP = stack_ldP(d);
-    const int slab_stride = d.total + 8;
+    // 64-float (256-byte) multiple: k_ppo_reduce's waves read 64 consecutive floats of every slab, and with a stride that is
+    // not a multiple of the 128-byte line each such read straddles three lines instead of two (round 3: FETCH_SIZE of the
+    // reduce 1.4-1.95x the slab bytes before)
+    const int slab_stride = (d.total + 8 + 63) & ~63;
     // slack rows: the last row tile may read past the last minibatch (owned mode: a short step still reads mbp rows)
     const int TNp = (int)TN + 64 + (owned ? mbp : 0);
 
@@ -359,6 +370,12 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     }
     const int wb_f = max_trunk_floats(d), wb_b = max_bwd_floats(d);
     const bool fused = ppo_fused(d, MT);
+    // SplitPolicy with more (row group, trunk) workgroups than CUs: the critic's whole fused forward + backward rides in the
+    // forward launch (k_ppo_fwd_critic), the backward launch covers the two actor trunks.  SG_PPO_CRITIC_FIRST=0/1 forces it.
+    const size_t lds_fc = sizeof(float) * ((size_t)wb_f + R * d.ldO + 2 * R * d.ldH + 2 * R * ldP + ((R * d.A + 3) & ~3) + 7 * R);
+    const char* cfenv = getenv("SG_PPO_CRITIC_FIRST");
+    const bool crit_first = !fused && d.kind == SG_POLICY_SPLIT && MT <= 2 && lds_fc <= (size_t)ctx->lds_bytes &&
+                            (cfenv ? cfenv[0] == '1' : G * d.n_trunks > ctx->num_cu);
     const size_t lds_f = ppo_fwd_lds(d, MT), lds_b = ppo_bwd_lds(d, MT);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
@@ -377,13 +394,20 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                 const size_t rb = (size_t)step_off[(size_t)e * M + k];
                 pa.mb = step_cnt[(size_t)e * M + k];
                 pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
-                if (!fused) {
-                    pa.wbuf_floats = wb_f;
-                    launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
-                }
-                pa.wbuf_floats = fused ? wb_f : wb_b;
                 pa.k1 = e * M + k + 1;
-                launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused);
+                if (crit_first) {
+                    pa.wbuf_floats = wb_f;
+                    launch_ppo_fwd_critic(ctx, MT, d, dim3(G, d.n_trunks), lds_fc > lds_f ? lds_fc : lds_f, pa);
+                    pa.wbuf_floats = wb_b;
+                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks - 1), lds_b, pa, false);   // trunks 0, 1: the actors
+                } else {
+                    if (!fused) {
+                        pa.wbuf_floats = wb_f;
+                        launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
+                    }
+                    pa.wbuf_floats = fused ? wb_f : wb_b;
+                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused);
+                }
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
                           d.total, a->d_grad, a->d_part);
                 if (ctx->use_comm) {
@@ -415,7 +439,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {

@@ -101,21 +101,21 @@ __global__ __launch_bounds__(256) void k_ppo_epoch_gather(EpochGatherArgs a) {
 
 // --------------------------------------------------------------------------------- forward
 template <int MT, int KO, int KH>
-__global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
+__device__ __forceinline__ void sg_ppo_fwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
     const SgPolicyDesc& d = a.d;
     const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
-    const int t = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
     const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP;
     float* W = smem;
     float* X = W + a.wbuf_floats;
     float* H1 = X + R * ldO;
     float* H2 = H1 + R * ldH;
-    const int row0 = blockIdx.x * R;
+    const int row0 = bx * R;
 
     SG_PPO_STAMP(0);
     float4 wv[12];
@@ -154,6 +154,11 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
     SG_PPO_STAMP(5);
 }
 
+template <int MT, int KO, int KH>
+__global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
+    sg_ppo_fwd_body<MT, KO, KH>(a, blockIdx.y, blockIdx.x);
+}
+
 // -------------------------------------------------------------------------------- backward
 // FUSED (Policy: the actor and critic trunks do not depend on each other's outputs): the workgroup stages the
 // whole trunk, recomputes the forward on its own rows in LDS and goes straight on to the loss -- no k_ppo_fwd
@@ -162,19 +167,18 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
 // (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per SIMD hide each
 // other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights staged once and
 // one slab per 32 rows.
-template <int MT, int KO, int KH, bool FUSED = false>
-__global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
+template <int MT, int KO, int KH, bool FUSED>
+__device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (No spare workgroup for Adam's bias corrections any more: with G x trunks = 256 row-group blocks, two extra blocks
     // made 258 for 256 CUs, and whenever the dispatcher doubled two row groups up on one CU before the spare blocks had
     // exited, those pairs finished 4 us after everyone else.  k_ppo_adam prepares the NEXT step's scalars instead.)
-    const int bx = blockIdx.x;   // row group
     constexpr int R = 16 * MT;
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
     const SgPolicyDesc& d = a.d;
     const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
-    const int t = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
     const bool critic = t == d.n_trunks - 1;
     const bool mlp = d.kind == SG_POLICY_MLP;
@@ -454,6 +458,23 @@ __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
     }
     SG_PPO_STAMP(15);
     SG_PPO_WALL(7);
+}
+
+template <int MT, int KO, int KH, bool FUSED = false>
+__global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
+    sg_ppo_bwd_body<MT, KO, KH, FUSED>(a, blockIdx.y, blockIdx.x);
+}
+
+// SplitPolicy at minibatches whose (row groups x 3 trunks) exceed the CU count: the critic trunk needs no actor output (its
+// loss is the value loss alone), so it does not have to wait at the forward -> backward seam of the two actor trunks (a row's
+// log-prob sums over both actors' heads).  This launch does the ACTORS' forward (blockIdx.y = 1, 2 -> trunks 0, 1) and the
+// CRITIC's whole fused forward + loss + backward (blockIdx.y = 0: dispatched first, they are the long blocks); the backward
+// launch that follows covers the two actor trunks only.  At 4096-row minibatches that is 384 + 256 workgroups on 256 CUs with
+// the critic's 128 long blocks beside two half-rounds of forward blocks, instead of 384 + 384 in two rounds each.
+template <int MT, int KO, int KH>
+__global__ __launch_bounds__(512) void k_ppo_fwd_critic(PpoArgs a) {
+    if (blockIdx.y == 0) sg_ppo_bwd_body<MT, KO, KH, true>(a, a.d.n_trunks - 1, blockIdx.x);
+    else sg_ppo_fwd_body<MT, KO, KH>(a, blockIdx.y - 1, blockIdx.x);
 }
 
 // grad[i] = sum over slabs; part[block] = sum of squares of this block's grads.  A block owns 64 consecutive
