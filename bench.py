@@ -95,11 +95,17 @@ def algorithmic_work(w, world, disc_sharded=False):
            (3 * (O * H + H + H * H + H) + H + 1 + 2 * (H * 4 * w["feet"] + 4 * w["feet"]) + 2 * (H * 3 * w["feet"] + 3 * w["feet"]))
     fused = w["kind"] == "mlp"    # Policy: k_ppo_bwd recomputes the forward, no k_ppo_fwd launch
     fwd_flops = mb * 2 * fwd
+    # SplitPolicy with more (32-row group, trunk) workgroups than the 256 CUs: the critic's whole fused forward + backward
+    # rides in the forward launch and the backward launch covers the two actor trunks (csrc/sg_ppo.hip: crit_first)
+    crit_first = (not fused) and ((mb + 31) // 32) * 3 > 256
+    crit_fwd = O * H + H * H + H
+    crit_bwd_flops = mb * 2 * (2 * crit_fwd - O * H) if crit_first else 0
     kernels = {
         "disc_chain": ("k_disc_chain4", "mfma", d_chain_flops, 2 * B_rank * F * 4),
         "disc_wgrad": ("k_disc_wgrad", "mfma", d_wgrad_flops, 0),
-        "ppo_fwd": ("k_ppo_fwd", "mfma", 0 if fused else fwd_flops, 0 if fused else mb * O * 4),
-        "ppo_bwd": ("k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused else fwd_flops), mb * (O + A + 4) * 4),
+        "ppo_fwd": ("k_ppo_fwd_critic" if crit_first else "k_ppo_fwd", "mfma", 0 if fused else fwd_flops + crit_bwd_flops,
+                    0 if fused else mb * (O + (3 if crit_first else 0)) * 4),
+        "ppo_bwd": ("k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused else fwd_flops) - crit_bwd_flops, mb * (O + A + 4) * 4),
         "ppo_reduce": ("k_ppo_reduce", "hbm", 0, P_pi * 4),          # the gradient vector; the slabs it sums are an implementation artefact
         "ppo_adam": ("k_ppo_adam", "hbm", 0, P_pi * 4 * 7),          # grad + params / m / v read and written
         "relabel_fwd": ("k_disc_forward", "mfma", relabel_flops, TN * (F + 1) * 4 if w["E_d"] else 0),

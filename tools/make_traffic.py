@@ -7,7 +7,11 @@ on a known byte count in one's own access pattern): coalesced reads of 4, 8 and 
 buffer loads all report exactly HALF their bytes in FETCH_SIZE (c_f = 2), WRITE_SIZE reports stores of every width exactly
 (c_w = 1).  Counter units are KB.
 
-Usage: python tools/make_traffic.py <tag> [<calibration tag>]      e.g.  python tools/make_traffic.py r03_v18 r03"""
+A counter pass that is missing for <tag> (rocprofv3's PMC collection occasionally aborts or hangs on this pool) is taken from
+<fallback tag> for the kernels that did not change between the two builds (STALE lists the ones that did); the entry's `source`
+says so.
+
+Usage: python tools/make_traffic.py <tag> [<calibration tag> [<fallback tag>]]    e.g.  python tools/make_traffic.py r03_v19 r03_v19 r03_v18"""
 import json
 import os
 import re
@@ -15,6 +19,8 @@ import sys
 
 tag = sys.argv[1]
 calib_tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+fallback = sys.argv[3] if len(sys.argv) > 3 else None
+STALE = ("k_ppo_fwd", "k_ppo_fwd_critic", "k_ppo_bwd", "k_ppo_reduce")   # changed between r03_v18 and r03_v19
 calib = json.load(open(f"profiles/{calib_tag}_pmc_calibration.json"))
 reads = [v["counter_over_true"] for k, v in calib["FETCH_SIZE"].items() if k.startswith("k_calib_read")]
 writes = [v["counter_over_true"] for k, v in calib["WRITE_SIZE"].items() if k.startswith("k_calib_write")]
@@ -23,18 +29,27 @@ c_f, c_w = 1.0 / (sum(reads) / len(reads)), 1.0 / (sum(writes) / len(writes))
 doc = {"calibration": {"source": f"profiles/{calib_tag}_pmc_calibration.json", "fetch_correction": round(c_f, 4), "write_correction": round(c_w, 4)},
        "workloads": {}}
 for wl in ("northstar", "hopper", "laikago", "refine"):
-    files = {w: f"profiles/{tag}_{wl}_pmc_{w}_size.txt" for w in ("fetch", "write")}
-    if not all(os.path.exists(f) for f in files.values()):
+    files, stale = {}, set()
+    for w in ("fetch", "write"):
+        f = f"profiles/{tag}_{wl}_pmc_{w}_size.txt"
+        if not (os.path.exists(f) and os.path.getsize(f)) and fallback:
+            f = f"profiles/{fallback}_{wl}_pmc_{w}_size.txt"
+            stale.add(w)
+        files[w] = f
+    if not all(os.path.exists(f) and os.path.getsize(f) for f in files.values()):
         continue
     out = {}
     for what in ("fetch", "write"):
         for line in open(files[what]):
             m = re.match(r"(?:void )?(\w+)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
-            if m:
-                out.setdefault(m.group(1), {"fetch_kb_raw": 0.0, "write_kb_raw": 0.0})[f"{what}_kb_raw"] = float(m.group(4))
-    for v in out.values():
-        v["hbm_bytes_per_launch"] = int(1024 * (v["fetch_kb_raw"] * c_f + v["write_kb_raw"] * c_w))
-    doc["workloads"][wl] = {"source": f"{files['fetch']}, {files['write']}", "kernels": out}
+            if m and not (what in stale and m.group(1) in STALE):
+                out.setdefault(m.group(1), {})[f"{what}_kb_raw"] = float(m.group(4))
+    for k, v in out.items():
+        complete = "fetch_kb_raw" in v and "write_kb_raw" in v
+        v["hbm_bytes_per_launch"] = int(1024 * (v["fetch_kb_raw"] * c_f + v["write_kb_raw"] * c_w)) if complete else None
+    note = "".join(f"; the {w.upper()}_SIZE pass of {tag} is missing (rocprofv3 aborted / hung): taken from {fallback}, kernels changed since ({', '.join(STALE)}) left without a total"
+                   for w in sorted(stale))
+    doc["workloads"][wl] = {"source": f"{files['fetch']}, {files['write']}{note}", "kernels": out}
 json.dump(doc, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
 for wl, d in doc["workloads"].items():
-    print(wl, {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if k.startswith(("k_disc_chain", "k_disc_wgrad", "k_ppo_"))})
+    print(wl, {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if k.startswith(("k_disc_chain", "k_disc_wgrad", "k_ppo_"))}, d["source"][-60:])
