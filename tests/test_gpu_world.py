@@ -312,6 +312,44 @@ def test_config4_per_rank_shape_prefix_world8():
     assert_close(res[0]["pi"], pi, what="SplitPolicy (Laikago) after the PPO epoch")
 
 
+def test_config5_per_rank_shape_world8():
+    """BASELINE.json configs[4]: Laikago policy refinement (a2c/main.py caller), 2048 envs sharded 8 ways -> 256 columns per
+    rank, obs 111 / act 12 / Policy h64, 8 minibatches, clip 0.1, lr 1.5e-4: one PPO epoch (8 steps on 32,768-row global
+    minibatches, the reference's permutation over the 262,144 global rows) against the oracle on the concatenated rollout."""
+    import simgan_amd as sg
+    from oracle import oracle as orc
+    from helpers import assert_close
+    world, T, N_loc, O, A, H = 8, 128, 256, 111, 12, 64
+    hp = dict(T=T, N_loc=N_loc, O=O, A=A, F=4, kind="mlp", H=H, feet=1, Hd=16, B=8, Ne=0, E=1, M=8, clip=0.1, ecoef=0.0)
+    g = make_global(world, T, N_loc, O, A, 4, "mlp", H, 1, 0, seed=6)
+    rng = np.random.default_rng(8)
+    perms = rng.permutation(T * g["Ng"]).astype(np.int64)[None]
+    next_value = rng.standard_normal(g["Ng"]).astype(np.float32)
+    ret, vp = oracle_returns(g, next_value)
+    pi, adam = g["pi"].copy(), orc.AdamState(g["pi"].size)
+    cfg = orc.ppo_cfg(0.1, 1, 8, 0.5, 0.0, 1.5e-4, 1e-5, 0.5, True)
+    want = orc.ppo_update(g["d"], pi, adam, cfg, g["obs"], g["actions"], vp, ret, g["logp"], perms)
+
+    def rank_fn(rank, ctx):
+        pol = sg.Policy((O,), Box((A,)), base_kwargs={"recurrent": False, "hidden_size": H}, ctx=ctx)
+        pol.set_flat_params(g["pi"])
+        agent = sg.algo.PPO(pol, 0.1, 1, 8, 0.5, 0.0, lr=1.5e-4, eps=1e-5, max_grad_norm=0.5)
+        ro = sg.RolloutStorage(T, N_loc, (O,), Box((A,)), 1, 4, ctx=ctx)
+        put = lambda dst, src: dst.copy_(dst.new_tensor(np.ascontiguousarray(src).reshape(tuple(dst.shape))))  # noqa: E731
+        for name, key in (("obs", "obs"), ("actions", "actions"), ("action_log_probs", "logp"), ("value_preds", "value_preds"),
+                          ("masks", "masks"), ("bad_masks", "bad_masks"), ("rewards", "rewards")):
+            put(getattr(ro, name), shard(g[key], rank, N_loc))
+        ro.compute_returns(next_value[rank * N_loc:(rank + 1) * N_loc], True, GAMMA, LAM, True)
+        return dict(losses=agent.update(ro, perms=perms), pi=pol.get_flat_params())
+
+    res = run_ranks(world, rank_fn, timeout_s=900)
+    for r in res[1:]:
+        assert np.array_equal(res[0]["pi"], r["pi"]), "replicas diverged"
+    assert_close(res[0]["losses"], want, what="PPO losses, refinement shape, world 8")
+    assert_close(res[0]["pi"], pi, what="policy after the epoch, refinement shape, world 8")
+    assert np.max(np.abs(pi - g["pi"])) > 1e-4
+
+
 @pytest.mark.parametrize("mode", ["replicated", "sharded"])
 def test_library_rng_update_world2_replays_through_the_oracle(mode):
     """The production path for N > 1 (no injected draws: the library's generator, device-resident rollouts, the drivers'
