@@ -15,6 +15,7 @@ from info["sas_window"], a2c/main_gail_dyn_ppo.py:220-226).
 """
 import collections.abc
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -65,7 +66,6 @@ class _ResultRing(object):
         self.ctx, self.n, self.live = ctx, 0, [None] * _RESULT_SLOTS
 
     def publish(self, disc, agent, keys):
-        import os
         slot = self.n % _RESULT_SLOTS
         self.n += 1
         if self.live[slot] is not None:

@@ -274,6 +274,22 @@ def test_checkpoint_reader_refuses_nested_unrestricted_unpickle(tmp_path):
     assert ("torch.storage", "_load_from_bytes") not in ck._ALLOWED
 
 
+def test_lazy_policy_keeps_its_pickled_state_when_the_device_twin_cannot_be_built():
+    """A Policy that torch.load is still assembling builds its device twin on first use (simgan_amd/model.py:_materialise).
+    If that fails -- here: a module state that is not a policy's -- the pickled state must survive and every later access must
+    raise the real cause again, not a bare AttributeError with the state gone (round-2 advisor finding)."""
+    from simgan_amd.model import Policy
+    p = Policy.__new__(Policy)
+    p.__setstate__({"_modules": {"nothing": None}, "_parameters": {}})
+    errs = []
+    for _ in range(2):
+        with pytest.raises(Exception) as ei:
+            p.num_params
+        errs.append((type(ei.value), str(ei.value)))
+        assert p.__dict__.get("_pending") is not None
+    assert errs[0] == errs[1] and not (errs[0][0] is AttributeError and errs[0][1] == "num_params")
+
+
 def test_no_fixture_carries_reference_source():
     """A fixture is data: torch's legacy container would embed the source text of every pickled nn.Module class
     (tools/gen_golden.py:save_legacy_without_source disables that)."""
