@@ -26,6 +26,11 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported
+ * (tests/test_abi.py checks both directions against `nm -D`).  Test hooks and probe kernels live in a
+ * separate libsimgan_hip_test.so (simgan_amd/csrc/sg_test_api.h), never in the product library. */
+#define SG_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -37,55 +42,55 @@ typedef struct sg_ppo sg_ppo;
 typedef struct sg_disc sg_disc;
 
 /* ------------------------------------------------------------------ context */
-const char *sg_last_error(void);
-const char *sg_version(void);
+SG_API const char *sg_last_error(void);
+SG_API const char *sg_version(void);
 /* Creates the context on HIP device `device` (one stream, scratch arenas). */
-int sg_ctx_create(int device, sg_ctx **out);
-int sg_ctx_destroy(sg_ctx *ctx);
-int sg_ctx_synchronize(sg_ctx *ctx);
+SG_API int sg_ctx_create(int device, sg_ctx **out);
+SG_API int sg_ctx_destroy(sg_ctx *ctx);
+SG_API int sg_ctx_synchronize(sg_ctx *ctx);
 /* Device properties the bench reports: name, CU count, HBM bytes. */
-int sg_ctx_device_info(sg_ctx *ctx, char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
+SG_API int sg_ctx_device_info(sg_ctx *ctx, char *name, int name_len, int *num_cu, int64_t *hbm_bytes);
 
 /* Data-parallel communicator over RCCL (one process per GPU, xGMI). Replaces nothing in the
  * reference (single process, a2c/main_gail_dyn_ppo.py:64); added per BASELINE.json north_star.
  * id is the 128-byte ncclUniqueId produced on rank 0 and broadcast by the host launcher. */
-int sg_comm_unique_id(uint8_t id[128]);
+SG_API int sg_comm_unique_id(uint8_t id[128]);
 /* An id for the LOOPBACK transport instead: `world` contexts of ONE host (threads or processes, any devices -- also all
  * on the same device) exchange through a shared-memory segment named by the id; sg_ctx_comm_init recognises the id's
  * tag.  Every world > 1 code path of the library then runs on a one-GPU box (tests, bench.py --loopback); it
  * synchronises the stream per collective and is not a performance path. */
-int sg_comm_loopback_id(uint8_t id[128]);
-int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
+SG_API int sg_comm_loopback_id(uint8_t id[128]);
+SG_API int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
 /* *kind = 0 no communicator, 1 RCCL, 2 loopback. */
-int sg_ctx_comm_kind(sg_ctx *ctx, int *kind);
+SG_API int sg_ctx_comm_kind(sg_ctx *ctx, int *kind);
 /* rank / world as the communicator itself reports them (ncclCommUserRank / ncclCommCount) once it exists. */
-int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
+SG_API int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
 /* Discriminator data-parallel mode for world > 1: 0 = replicated (default: one all-gather of
  * the ranks' rows per epoch, identical full-batch steps everywhere), 1 = sharded (batch/world rows per rank and one
  * gradient all-reduce per step).  Initial value: SG_DISC_DP=sharded in the environment. */
-int sg_ctx_set_disc_dp(sg_ctx *ctx, int sharded);
+SG_API int sg_ctx_set_disc_dp(sg_ctx *ctx, int sharded);
 
 /* ------------------------------------------------------------------- policy */
 enum { SG_POLICY_MLP = 0, SG_POLICY_SPLIT = 1 };
 /* Policy(obs_shape, action_space, base_kwargs)            a2c/model.py:38-67   (kind MLP)
  * SplitPolicy(obs_shape, action_space, base_kwargs)       a2c/model_split.py:40-52 (kind SPLIT;
  * requires act_dim == 7*num_feet, a2c/model_split.py:205). Parameters start at zero. */
-int sg_policy_create(sg_ctx *ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet,
+SG_API int sg_policy_create(sg_ctx *ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet,
                      sg_policy **out);
-int sg_policy_destroy(sg_policy *p);
-int sg_policy_num_params(const sg_policy *p, int64_t *n);
+SG_API int sg_policy_destroy(sg_policy *p);
+SG_API int sg_policy_num_params(const sg_policy *p, int64_t *n);
 /* nn.Module.load_state_dict / state_dict, flattened. */
-int sg_policy_set_params(sg_policy *p, const float *flat, int64_t n);
-int sg_policy_get_params(sg_policy *p, float *flat, int64_t n);
+SG_API int sg_policy_set_params(sg_policy *p, const float *flat, int64_t n);
+SG_API int sg_policy_get_params(sg_policy *p, float *flat, int64_t n);
 /* Policy.act a2c/model.py:89-101, SplitPolicy.act a2c/model_split.py:70-82.
  * obs[n,O]; noise[n,A] standard normal draws or NULL (-> library RNG with `seed`);
  * deterministic != 0 -> dist.mode().  Outputs value[n], action[n,A], logp[n]. */
-int sg_policy_act(sg_policy *p, const float *obs, int n, const float *noise, uint64_t seed,
+SG_API int sg_policy_act(sg_policy *p, const float *obs, int n, const float *noise, uint64_t seed,
                   int deterministic, float *value, float *action, float *logp);
 /* Policy.get_value a2c/model.py:103-105 */
-int sg_policy_get_value(sg_policy *p, const float *obs, int n, float *value);
+SG_API int sg_policy_get_value(sg_policy *p, const float *obs, int n, float *value);
 /* Policy.evaluate_actions a2c/model.py:107-114: value[n], logp[n], *entropy = dist.entropy().mean() */
-int sg_policy_evaluate(sg_policy *p, const float *obs, const float *action, int n, float *value,
+SG_API int sg_policy_evaluate(sg_policy *p, const float *obs, const float *action, int n, float *value,
                        float *logp, float *entropy);
 /* The policies that live INSIDE the reference's hybrid-sim environments, batched over the N environments of a
  * pool: every worker calls a batch-1 actor_critic.act per step, in refinement mode on one of five saved dynamics
@@ -94,7 +99,7 @@ int sg_policy_evaluate(sg_policy *p, const float *obs, const float *action, int 
  * policies[idx[i]] (0 <= idx[i] < n_policies <= SG_ENSEMBLE_MAX, all members the same kind and shape, weights
  * resident).  noise / seed / deterministic and the outputs are as in sg_policy_act. */
 #define SG_ENSEMBLE_MAX 8
-int sg_policy_act_ensemble(sg_policy *const *policies, int n_policies, const int32_t *idx, const float *obs,
+SG_API int sg_policy_act_ensemble(sg_policy *const *policies, int n_policies, const int32_t *idx, const float *obs,
                            int n, const float *noise, uint64_t seed, int deterministic, float *value,
                            float *action, float *logp);
 
@@ -114,26 +119,26 @@ enum {
     SG_F_ADVANTAGES = 9,   /* [T,   N]  normalised advantages of the last sg_ppo_update (read-only) */
     SG_F_COUNT = 10
 };
-int sg_rollout_create(sg_ctx *ctx, int T, int N, int obs_dim, int act_dim, int feat_dim,
+SG_API int sg_rollout_create(sg_ctx *ctx, int T, int N, int obs_dim, int act_dim, int feat_dim,
                       sg_rollout **out);
-int sg_rollout_destroy(sg_rollout *r);
+SG_API int sg_rollout_destroy(sg_rollout *r);
 /* Whole-field host<->device copies; count = number of floats (must equal the field size). */
-int sg_rollout_upload(sg_rollout *r, int field, const float *host, int64_t count);
-int sg_rollout_download(sg_rollout *r, int field, float *host, int64_t count);
+SG_API int sg_rollout_upload(sg_rollout *r, int field, const float *host, int64_t count);
+SG_API int sg_rollout_download(sg_rollout *r, int field, float *host, int64_t count);
 /* One time-slot [t] of a field (N * width floats): the reference's rollouts.obs[step].copy_(..). */
-int sg_rollout_upload_step(sg_rollout *r, int field, int t, const float *host, int64_t count);
-int sg_rollout_download_step(sg_rollout *r, int field, int t, float *host, int64_t count);
+SG_API int sg_rollout_upload_step(sg_rollout *r, int field, int t, const float *host, int64_t count);
+SG_API int sg_rollout_download_step(sg_rollout *r, int field, int t, float *host, int64_t count);
 /* RolloutStorage.after_update a2c/storage.py:96-101: slot T -> slot 0 for obs, obs_feat, masks, bad_masks */
-int sg_rollout_after_update(sg_rollout *r);
+SG_API int sg_rollout_after_update(sg_rollout *r);
 /* RolloutStorage.compute_returns a2c/storage.py:103-142 (all four branches); next_value[N] host. */
-int sg_rollout_compute_returns(sg_rollout *r, const float *next_value, int use_gae, float gamma,
+SG_API int sg_rollout_compute_returns(sg_rollout *r, const float *next_value, int use_gae, float gamma,
                                float gae_lambda, int use_proper_time_limits);
 /* Same, with next_value = policy.get_value(obs[T]) computed on device (a2c/main_gail_dyn_ppo.py:239-242,299). */
-int sg_rollout_compute_returns_policy(sg_rollout *r, sg_policy *p, int use_gae, float gamma,
+SG_API int sg_rollout_compute_returns_policy(sg_rollout *r, sg_policy *p, int use_gae, float gamma,
                                       float gae_lambda, int use_proper_time_limits);
 /* Synthetic rollout fill on device for benchmarks: obs, obs_feat ~ N(0,1);
  * actions/logp/value_preds from policy.act; masks ~ Bernoulli(1-p_done); bad_masks = 1. */
-int sg_rollout_fill_synthetic(sg_rollout *r, sg_policy *p, uint64_t seed, float p_done);
+SG_API int sg_rollout_fill_synthetic(sg_rollout *r, sg_policy *p, uint64_t seed, float p_done);
 
 /* ---------------------------------------------------------------------- PPO */
 typedef struct {
@@ -149,17 +154,17 @@ typedef struct {
 } sg_ppo_config;
 /* PPO(actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef, lr, eps,
  *     max_grad_norm, use_clipped_value_loss)  a2c/algo/ppo.py:30-63 (Adam state starts at zero). */
-int sg_ppo_create(sg_ctx *ctx, sg_policy *p, const sg_ppo_config *cfg, sg_ppo **out);
-int sg_ppo_destroy(sg_ppo *a);
+SG_API int sg_ppo_create(sg_ctx *ctx, sg_policy *p, const sg_ppo_config *cfg, sg_ppo **out);
+SG_API int sg_ppo_destroy(sg_ppo *a);
 /* optimizer.param_groups[i]['lr'] = lr  (a2c/utils.py:68-72 update_linear_schedule) */
-int sg_ppo_set_lr(sg_ppo *a, float lr);
+SG_API int sg_ppo_set_lr(sg_ppo *a, float lr);
 /* PPO.update(rollouts) a2c/algo/ppo.py:65-157 -> out3 = {value_loss, action_loss, dist_entropy}.
  * perms: [ppo_epoch][T*N] int64 = the permutation each epoch's sampler draws (a2c/storage.py:159-162) with n_perms =
  * its element count (checked, as is every index), or NULL (n_perms ignored) -> device-generated from `seed`.
  * With a communicator of world > 1 an injected permutation is the reference's draw at num_processes = world * N:
  * [ppo_epoch][T*N*world] ids in its numbering t*(N*world) + rank*N + n, the same array on every rank; each rank takes
  * the rows of every minibatch it owns (NULL: every rank permutes its own rows and gives T*N/num_mini_batch per step). */
-int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, int64_t n_perms, uint64_t seed, float out3[3]);
+SG_API int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, int64_t n_perms, uint64_t seed, float out3[3]);
 /* out3 may be NULL (as for sg_disc_update_gail_dyn): the update is queued and the call returns without waiting for it.
  * An outer iteration made of such calls -- sg_disc_update_gail_dyn x gail_epoch, sg_disc_relabel_rewards_auto,
  * sg_rollout_compute_returns_policy, sg_ppo_update, sg_rollout_after_update -- never makes the host wait; its scalars (the
@@ -167,26 +172,26 @@ int sg_ppo_update(sg_ppo *a, sg_rollout *r, const int64_t *perms, int64_t n_perm
  * host slots by sg_results_publish (d and/or a may be NULL) and read with sg_results_fetch when the caller wants them:
  * out13 = {D loss sums x3 of the last epoch, ret_rms mean / var / count, sum(1 - masks), r_sa, PPO loss sums x3,
  * n_d, ppo_epoch * num_mini_batch}; losses = sums / their step count (float32, as the synchronous calls return them). */
-int sg_results_publish(sg_ctx *ctx, sg_disc *d, sg_ppo *a, int slot);
-int sg_results_fetch(sg_ctx *ctx, int slot, double out13[13]);
+SG_API int sg_results_publish(sg_ctx *ctx, sg_disc *d, sg_ppo *a, int slot);
+SG_API int sg_results_fetch(sg_ctx *ctx, int slot, double out13[13]);
 /* Adam state access for checkpoint/parity: m, v flat [n] in state_dict order; *step = t. */
 /* The permutations the last sg_ppo_update consumed ([ppo_epoch][T*N], injected or library-drawn), so a run made
  * with the library's generator can be replayed elsewhere (the role torch.manual_seed plays for the reference). */
-int sg_ppo_last_perms(sg_ppo *a, int64_t *perms, int64_t count);
-int sg_ppo_get_adam(sg_ppo *a, float *m, float *v, int64_t n, int64_t *step);
-int sg_ppo_set_adam(sg_ppo *a, const float *m, const float *v, int64_t n, int64_t step);
+SG_API int sg_ppo_last_perms(sg_ppo *a, int64_t *perms, int64_t count);
+SG_API int sg_ppo_get_adam(sg_ppo *a, float *m, float *v, int64_t n, int64_t *step);
+SG_API int sg_ppo_set_adam(sg_ppo *a, const float *m, const float *v, int64_t n, int64_t step);
 
 /* ------------------------------------------------------------ discriminator */
 /* Discriminator(input_dim, hidden_dim, device) a2c/algo/gail.py:35-51; Adam(lr 1e-3, eps 1e-8). */
-int sg_disc_create(sg_ctx *ctx, int input_dim, int hidden_dim, sg_disc **out);
-int sg_disc_destroy(sg_disc *d);
-int sg_disc_num_params(const sg_disc *d, int64_t *n);
-int sg_disc_set_params(sg_disc *d, const float *flat, int64_t n);
-int sg_disc_get_params(sg_disc *d, float *flat, int64_t n);
-int sg_disc_get_adam(sg_disc *d, float *m, float *v, int64_t n, int64_t *step);
-int sg_disc_set_adam(sg_disc *d, const float *m, const float *v, int64_t n, int64_t step);
+SG_API int sg_disc_create(sg_ctx *ctx, int input_dim, int hidden_dim, sg_disc **out);
+SG_API int sg_disc_destroy(sg_disc *d);
+SG_API int sg_disc_num_params(const sg_disc *d, int64_t *n);
+SG_API int sg_disc_set_params(sg_disc *d, const float *flat, int64_t n);
+SG_API int sg_disc_get_params(sg_disc *d, float *flat, int64_t n);
+SG_API int sg_disc_get_adam(sg_disc *d, float *m, float *v, int64_t n, int64_t *step);
+SG_API int sg_disc_set_adam(sg_disc *d, const float *m, const float *v, int64_t n, int64_t step);
 /* The expert matrix [n_rows, input_dim] (a2c/main_gail_dyn_ppo.py:163-165) stays resident in HBM. */
-int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
+SG_API int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
 /* Discriminator.update_gail_dyn(expert_loader, rollouts) a2c/algo/gail.py:154-193, one epoch.
  * batch_size = expert_loader.batch_size; n_d = min(n_expert/batch, T*N/batch) steps.
  * expert_perm[n_expert] (DataLoader shuffle), policy_perm[T*N] (feed_forward_generator),
@@ -200,7 +205,7 @@ int sg_disc_set_expert(sg_disc *d, const float *expert, int64_t n_rows);
  * has no use for this epoch's losses (the reference's main keeps only the last epoch's, a2c/main_gail_dyn_ppo.py:255-256):
  * the call then returns as soon as the epoch is queued instead of waiting for it.
  * n_expert < batch_size is an error (the reference raises on the size mismatch). */
-int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm, int64_t n_expert_perm,
+SG_API int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int64_t *expert_perm, int64_t n_expert_perm,
                             const int64_t *policy_perm, int64_t n_policy_perm, const float *alpha, int64_t n_alpha,
                             uint64_t seed, float out3[3], int *n_steps);
 /* Discriminator.update(expert_loader, rollouts, obsfilt, is_gail_dyn, a_dim) a2c/algo/gail.py:91-152, one
@@ -210,40 +215,40 @@ int sg_disc_update_gail_dyn(sg_disc *d, sg_rollout *r, int batch_size, const int
  * policy_perm ranges over n_rows (x world with a communicator).  n_cols = environment columns per time slot when the
  * rows are a rollout's (t, n) grid (needed to number the union of the ranks' rows as the reference would at
  * num_processes = world*N), 0 = unstructured rows (the union is numbered rank after rank). */
-int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, int n_cols, int batch_size,
+SG_API int sg_disc_update_rows(sg_disc *d, const float *policy_rows, int64_t n_rows, int n_cols, int batch_size,
                         const int64_t *expert_perm, int64_t n_expert_perm, const int64_t *policy_perm, int64_t n_policy_perm,
                         const float *alpha, int64_t n_alpha, uint64_t seed, float out3[3], int *n_steps);
 /* Discriminator.predict_reward_combined(d_in, gamma, masks, offset) a2c/algo/gail.py:201-210.
  * x[n,F], masks[n] -> reward[n], returns[n]; Discriminator.returns persists inside the handle
  * (first call: returns = reward).  n must stay the same across calls. */
-int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma, const float *masks,
+SG_API int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma, const float *masks,
                            float offset, float *reward, float *returns);
 /* Discriminator.predict_prob_single_step(s, a, s_n) a2c/algo/gail.py:212-217: prob[n] = sigmoid(D(x)) on the
  * caller-concatenated rows x[n,F]. */
-int sg_disc_predict_prob(sg_disc *d, const float *x, int n, float *prob);
+SG_API int sg_disc_predict_prob(sg_disc *d, const float *x, int n, float *prob);
 /* The draws the last update epoch consumed: expert_perm[n_expert], policy_perm[n_policy_rows], alpha[n_alpha]
  * (injected or library-drawn); each pointer may be NULL, each count must match the epoch's size (returned in
  * counts3 = {n_expert, n_policy_rows, n_alpha} when counts3 != NULL). */
-int sg_disc_last_draws(sg_disc *d, int64_t *expert_perm, int64_t *policy_perm, float *alpha, int64_t counts3[3]);
-int sg_disc_reset_returns(sg_disc *d);
-int sg_disc_get_returns(sg_disc *d, float *returns, int n, int *is_none);
-int sg_disc_set_returns(sg_disc *d, const float *returns, int n);
+SG_API int sg_disc_last_draws(sg_disc *d, int64_t *expert_perm, int64_t *policy_perm, float *alpha, int64_t counts3[3]);
+SG_API int sg_disc_reset_returns(sg_disc *d);
+SG_API int sg_disc_get_returns(sg_disc *d, float *returns, int n, int *is_none);
+SG_API int sg_disc_set_returns(sg_disc *d, const float *returns, int n);
 /* Fused reward relabel, all T steps on device: a2c/main_gail_dyn_ppo.py:275-292
  *   for t: rewards[t], ret = predict_reward_combined(obs_feat[t+1], gamma, masks[t], offset)
  *          ret_rms.update(ret); rewards[t] = clip(rewards[t]/sqrt(ret_rms.var+1e-7), -10, 10)
  * rms_state = {mean, var, count} float64 (RunningMeanStd, a2c/baselines/common/running_mean_std.py:27-58),
  * updated in place.  Writes rollout field REWARDS. */
-int sg_disc_relabel_rewards(sg_disc *d, sg_rollout *r, float gamma, float offset,
+SG_API int sg_disc_relabel_rewards(sg_disc *d, sg_rollout *r, float gamma, float offset,
                             double rms_state[3]);
 /* The same with the alive-bonus offset computed on the device as well (a2c/main_gail_dyn_ppo.py:258-271: r_sa from
  * sum(1 - masks), num_processes (all ranks), num_steps and gail_tar_length; no_alive_bonus != 0 -> 0) and ret_rms kept inside
  * the handle (initially RunningMeanStd(): {0, 1, 1e-4}): nothing is read back, the call only queues work.
  * sg_disc_set_rms overwrites the resident state; sg_disc_get_scalars reads {mean, var, count, sum(1 - masks), r_sa}. */
-int sg_disc_relabel_rewards_auto(sg_disc *d, sg_rollout *r, float gamma, double gail_tar_length, int no_alive_bonus);
-int sg_disc_set_rms(sg_disc *d, const double rms_state[3]);
-int sg_disc_get_scalars(sg_disc *d, double out5[5]);
+SG_API int sg_disc_relabel_rewards_auto(sg_disc *d, sg_rollout *r, float gamma, double gail_tar_length, int no_alive_bonus);
+SG_API int sg_disc_set_rms(sg_disc *d, const double rms_state[3]);
+SG_API int sg_disc_get_scalars(sg_disc *d, double out5[5]);
 /* sum(1 - masks) over all T+1 slots (a2c/main_gail_dyn_ppo.py:258), for the alive-bonus offset. */
-int sg_rollout_count_dones(sg_rollout *r, double *dones);
+SG_API int sg_rollout_count_dones(sg_rollout *r, double *dones);
 
 /* ------------------------------------------------------------- measurement */
 /* HIP-event timing of the dominant kernels on the library's stream since the last reset:
@@ -251,14 +256,9 @@ int sg_rollout_count_dones(sg_rollout *r, double *dones);
  * 2 k_ppo_fwd, 3 k_ppo_bwd, 4 k_ppo_reduce, 5 relabel forward, 6 k_ppo_adam (clip + Adam).
  * Enabled by sg_ctx_profile(ctx, 1); adds start/stop events to every launch (do not enable inside
  * the timed bench region). */
-int sg_ctx_profile(sg_ctx *ctx, int enable);
-int sg_ctx_profile_read(sg_ctx *ctx, int which, double *total_ms, int64_t *launches);
-int sg_ctx_profile_reset(sg_ctx *ctx);
-
-/* Test hook: C[M,N] = op(A) op(B) through the LDS/MFMA tile engine (mode 0 NT, 1 NN, 2 TN),
- * all dims multiples of 16, host pointers.  Used by tests/test_gemm_engine.py only. */
-int sg_test_gemm(sg_ctx *ctx, int mode, int M, int N, int K, const float *A, const float *B,
-                 float *C);
+SG_API int sg_ctx_profile(sg_ctx *ctx, int enable);
+SG_API int sg_ctx_profile_read(sg_ctx *ctx, int which, double *total_ms, int64_t *launches);
+SG_API int sg_ctx_profile_reset(sg_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -102,8 +102,25 @@ PROTOTYPES = {
     "sg_ctx_profile": (C.c_int, [H, C.c_int]),
     "sg_ctx_profile_read": (C.c_int, [H, C.c_int, c_double_p, c_i64_p]),
     "sg_ctx_profile_reset": (C.c_int, [H]),
-    "sg_test_gemm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p]),
 }
+
+# libsimgan_hip_test.so (csrc/sg_test_api.h): test hooks and probes, for tests/ and tools/ only
+TEST_LIB_PATH = os.path.join(_HERE, "libsimgan_hip_test.so")
+c_ll_p = C.POINTER(C.c_longlong)
+TEST_PROTOTYPES = {
+    "sg_test_last_error": (C.c_char_p, []),
+    "sg_test_gemm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p]),
+    "sg_test_gemm_bench": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p]),
+    "sg_test_mfma_probe": (C.c_int, [H, C.c_int, c_float_p, c_float_p, c_float_p]),
+    "sg_test_flag_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p, c_float_p]),
+    "sg_test_fetch_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_ll_p]),
+    "sg_test_pmc_calibrate": (C.c_int, [H, C.c_int64]),
+    "sg_test_graph_state": (C.c_int, [H, H, c_int_p]),
+    "sg_test_disc_phase_times": (C.c_int, [H, C.c_int, c_ll_p, C.c_int]),
+    "sg_test_ppo_phase_times": (C.c_int, [H, C.c_int, c_ll_p, C.c_int]),
+    "sg_test_rng": (C.c_int, [H, C.c_int, C.c_int64, C.c_uint64, C.c_void_p]),
+}
+_TEST_LIB = None
 
 _LIB = None
 
@@ -133,6 +150,29 @@ def load():
 def check(rc):
     if rc != 0:
         raise SimganHipError(load().sg_last_error().decode(errors="replace"))
+
+
+def load_test():
+    """The test-hook library (never loaded by the product path).  The product library is loaded first: both share the
+    process's HIP runtime and the hooks operate on its handles."""
+    global _TEST_LIB
+    if _TEST_LIB is not None:
+        return _TEST_LIB
+    load()
+    if not os.path.exists(TEST_LIB_PATH):
+        raise SimganHipError(f"{TEST_LIB_PATH} not found: run `make -C simgan_amd/csrc`")
+    lib = C.CDLL(TEST_LIB_PATH)
+    for name, (res, args) in TEST_PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _TEST_LIB = lib
+    return lib
+
+
+def check_test(rc):
+    if rc != 0:
+        raise SimganHipError(load_test().sg_test_last_error().decode(errors="replace"))
 
 
 def fptr(a):

@@ -115,7 +115,7 @@ static void lb_name(const uint8_t id[128], char out[64]) {
     out[n] = 0;
 }
 
-static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
+static int lb_open_inner(SgLoopback* lb, const uint8_t id[128], int rank, int world, bool* created) {
     SG_REQUIRE(world <= 64, "loopback communicator: at most 64 ranks");
     char name[64];
     lb_name(id, name);
@@ -128,8 +128,9 @@ static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
     if (rank == 0) {
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         SG_REQUIRE(fd >= 0, "loopback communicator: shm_open(%s) failed: %s", name, strerror(errno));
+        *created = true;
         lb->map_bytes = hdr_bytes + 2 * (size_t)world * slot;     // sparse: pages are committed when first touched
-        if (ftruncate(fd, (off_t)lb->map_bytes) != 0) { close(fd); shm_unlink(name); SG_REQUIRE(false, "loopback communicator: ftruncate failed: %s", strerror(errno)); }
+        if (ftruncate(fd, (off_t)lb->map_bytes) != 0) { close(fd); SG_REQUIRE(false, "loopback communicator: ftruncate failed: %s", strerror(errno)); }
     } else {
         for (;;) {   // rank 0 creates the segment; wait until it exists and has its final size
             fd = shm_open(name, O_RDWR, 0600);
@@ -159,8 +160,21 @@ static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
     }
     SG_REQUIRE(lb->hdr->attached[rank].exchange(1) == 0, "loopback communicator: rank %d attached twice", rank);
     SG_TRY(lb_barrier(lb, "communicator set-up"));
-    if (rank == 0) shm_unlink(name);   // every rank has mapped it: the name can go, the memory lives until the last munmap
     return 0;
+}
+
+// The segment's NAME is needed only until every rank has mapped it; rank 0 removes it on success (the memory lives until the
+// last munmap) and on EVERY failure after it created it -- a failed mmap, a peer that died or timed out before the set-up
+// barrier -- so a broken start-up leaves nothing behind in /dev/shm.
+static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
+    bool created = false;
+    const int rc = lb_open_inner(lb, id, rank, world, &created);
+    if (created) {
+        char name[64];
+        lb_name(id, name);
+        shm_unlink(name);
+    }
+    return rc;
 }
 
 static int lb_tmp(SgLoopback* lb, size_t bytes) {

@@ -487,6 +487,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             hipLaunchKernelGGL(k_fill_alpha, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream, d->d_alpha, na,
                                seed, 0xA1000000ull + d->rng_calls);
         }
+        // a queued epoch (out3 == NULL) returns without a host wait: the caller's arrays must have been read by then
+        if (!out3 && (expert_perm || policy_perm || alpha)) SG_CHECK(hipStreamSynchronize(ctx->stream));
     }
 
     const int G = (B_loc + 15) / 16;
@@ -820,21 +822,5 @@ extern "C" int sg_disc_set_rms(sg_disc* d, const double rms_state[3]) {
 extern "C" int sg_disc_get_scalars(sg_disc* d, double out5[5]) {
     SG_REQUIRE(d && out5, "sg_disc_get_scalars: NULL argument");
     SG_COPY_SYNC(d->ctx, out5, d->d_scal, sizeof(double) * 5, hipMemcpyDeviceToHost);
-    return 0;
-}
-
-// Test hook: enable/read per-phase shader-clock timestamps of k_disc_chain (tools/phase_times.py).
-extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, int n_blocks) {
-    SG_REQUIRE(d, "sg_test_disc_phase_times: NULL argument");
-    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    if (enable && !d->d_dbg) {
-        SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 512));
-        SG_CHECK(hipMemsetAsync(d->d_dbg, 0, sizeof(long long) * 32 * 512, d->ctx->stream)); SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    }
-    if (out && d->d_dbg) {
-        SG_REQUIRE(n_blocks <= 512, "sg_test_disc_phase_times: at most 512 blocks");
-        SG_COPY_SYNC(d->ctx, out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost);   // n_blocks = 512: + k_disc_wgrad stamps
-    }
-    if (!enable && d->d_dbg) { SG_CHECK(hipFree(d->d_dbg)); d->d_dbg = nullptr; }
     return 0;
 }

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "sg_common.h"
@@ -161,6 +162,7 @@ __global__ void k_set_lr(SgOptState* st, float lr) { st->lr = lr; }
 
 extern "C" int sg_ppo_set_lr(sg_ppo* a, float lr) {
     SG_REQUIRE(a, "sg_ppo_set_lr: NULL argument");
+    SG_CHECK(hipSetDevice(a->ctx->device));
     a->cfg.lr = lr;
     // by kernel argument, in stream order: no host synchronisation (the schedule writes it before every update)
     hipLaunchKernelGGL(k_set_lr, dim3(1), dim3(1), 0, a->ctx->stream, reinterpret_cast<SgOptState*>(a->d_state), lr);
@@ -247,14 +249,26 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         mb_global = TN_perm / M;
         own_perm.assign((size_t)E * TN, 0);
         mb = 1;
+        std::vector<uint8_t> seen((size_t)TN_perm);
         for (int e = 0; e < E; ++e) {
+            // every epoch's row must be a true permutation (a2c/storage.py:159-162 draws one): with repeated ids a rank could
+            // be handed more than its T*N rows, past the end of own_perm and of the device's epoch copy
+            std::fill(seen.begin(), seen.end(), (uint8_t)0);
+            for (int64_t i = 0; i < TN_perm; ++i) {
+                const int64_t g = perms[(size_t)e * TN_perm + i];
+                SG_REQUIRE(!seen[(size_t)g], "sg_ppo_update: perms of epoch %d repeat row id %lld: not a permutation", e, (long long)g);
+                seen[(size_t)g] = 1;
+            }
             int64_t n_own = 0;
             for (int k = 0; k < M; ++k) {
                 step_off[(size_t)e * M + k] = (int)n_own;
                 for (int64_t i = 0; i < mb_global; ++i) {
                     const int64_t g = perms[(size_t)e * TN_perm + (size_t)k * mb_global + i];
                     const int64_t t = g / Ng, c = g - t * Ng, owner = c / r->N;
-                    if (owner == ctx->rank) own_perm[(size_t)e * TN + n_own++] = t * r->N + (c - owner * r->N);
+                    if (owner == ctx->rank) {
+                        SG_REQUIRE(n_own < TN, "sg_ppo_update: epoch %d hands this rank more than its %lld rows", e, (long long)TN);
+                        own_perm[(size_t)e * TN + n_own++] = t * r->N + (c - owner * r->N);
+                    }
                 }
                 const int cnt = (int)n_own - step_off[(size_t)e * M + k];
                 step_cnt[(size_t)e * M + k] = cnt;
@@ -293,6 +307,8 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         SG_CHECK(hipStreamSynchronize(ctx->stream));   // own_perm goes out of scope with this call
     } else if (perms) {
         SG_CHECK(hipMemcpyAsync(a->d_perms, perms, sizeof(int64_t) * (size_t)E * TN, hipMemcpyHostToDevice, ctx->stream));
+        // a queued update (out3 == NULL) returns without a host wait: the caller's array must have been read by then
+        if (!out3) SG_CHECK(hipStreamSynchronize(ctx->stream));
     } else {
         for (int e = 0; e < E; ++e)
             SG_TRY(sg_fill_perm(ctx, a->d_perms + (size_t)e * TN, TN, seed, (uint64_t)e * 2654435761ull + (uint64_t)ctx->rank));
@@ -491,46 +507,5 @@ extern "C" int sg_results_fetch(sg_ctx* ctx, int slot, double out13[13]) {
     SG_REQUIRE(ctx && out13 && slot >= 0 && slot < SG_RESULT_SLOTS, "sg_results_fetch: bad argument");
     SG_CHECK(hipEventSynchronize(ctx->res_ev[slot]));
     memcpy(out13, ctx->results + 16 * slot, sizeof(double) * 13);
-    return 0;
-}
-
-// Test hook: per-phase shader-clock timestamps of k_ppo_fwd, row groups [0, n_blocks) (tools/ppo_phase_times.py).
-extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, int n_blocks) {
-    SG_REQUIRE(a, "sg_test_ppo_phase_times: NULL argument");
-    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
-    if (enable && !a->d_dbg) {
-        SG_CHECK(hipMalloc((void**)&a->d_dbg, sizeof(long long) * 16 * 1024));
-        SG_CHECK(hipMemsetAsync(a->d_dbg, 0, sizeof(long long) * 16 * 1024, a->ctx->stream)); SG_CHECK(hipStreamSynchronize(a->ctx->stream));
-    }
-    if (out && a->d_dbg) {
-        SG_REQUIRE(n_blocks <= 1024, "sg_test_ppo_phase_times: at most 1024 blocks");
-        SG_COPY_SYNC(a->ctx, out, a->d_dbg, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost);
-    }
-    if (!enable && a->d_dbg) { SG_CHECK(hipFree(a->d_dbg)); a->d_dbg = nullptr; }
-    return 0;
-}
-
-// Test hook: the library's counter-based generators as host arrays (tests/test_gpu_fullsize.py).
-// kind 0: random permutation of [0, n) -> int64 out;  1: uniform [0,1) -> float out;  2: normal -> float out.
-__global__ void k_test_rng(float* out, int64_t n, uint64_t seed, int kind) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = kind == 1 ? sg_uniform(seed, 7, (uint64_t)i) : sg_normal(seed, 7, (uint64_t)i);
-}
-
-extern "C" int sg_test_rng(sg_ctx* ctx, int kind, int64_t n, uint64_t seed, void* out) {
-    SG_REQUIRE(ctx && out && n > 0 && kind >= 0 && kind <= 2, "sg_test_rng: bad argument");
-    SG_CHECK(hipSetDevice(ctx->device));
-    void* dev = nullptr;
-    SG_CHECK(hipMalloc(&dev, (size_t)n * 8));
-    if (kind == 0) {
-        SG_TRY(sg_fill_perm(ctx, (int64_t*)dev, n, seed, 3));
-        SG_CHECK(hipStreamSynchronize(ctx->stream));
-        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 8, hipMemcpyDeviceToHost);
-    } else {
-        hipLaunchKernelGGL(k_test_rng, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)dev, n, seed, kind);
-        SG_CHECK(hipStreamSynchronize(ctx->stream));
-        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 4, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(dev);
     return 0;
 }

@@ -1,8 +1,27 @@
-// sg_test.hip -- test hook for the LDS/MFMA tile engine (tests/test_gemm_engine.py).
+// sg_test.hip -- libsimgan_hip_test.so: test hooks and probe kernels (engine unit tests, phase-timestamp switches, RNG
+// dumps, latency / fetch / counter-calibration probes).  Built from this file alone and loaded only by tests/ and tools/
+// (simgan_amd/_lib.py:load_test); the product library exports none of it.  The hooks reach into handles created by the
+// product library through the struct definitions of sg_common.h -- both libraries are built from the same headers and
+// share the process's HIP runtime.
+#include <stdarg.h>
+#include <stdio.h>
+
 #include <vector>
 
 #include "sg_common.h"
+#include "sg_rng.hpp"
+#include "sg_test_api.h"
 #include "sg_thin.hpp"
+
+// this library's own error slot (the product's sg_set_error is not exported)
+static thread_local char g_test_err[1024] = "";
+void sg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_test_err, sizeof g_test_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sg_test_last_error(void) { return g_test_err; }
 
 struct GemmTestArgs {
     int mode, M, N, K;
@@ -512,5 +531,69 @@ extern "C" int sg_test_pmc_calibrate(sg_ctx* ctx, int64_t mbytes) {
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    return 0;
+}
+
+// Test hook: enable/read per-phase shader-clock timestamps of k_disc_chain (tools/phase_times.py).
+extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, int n_blocks) {
+    SG_REQUIRE(d, "sg_test_disc_phase_times: NULL argument");
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    if (enable && !d->d_dbg) {
+        SG_CHECK(hipMalloc((void**)&d->d_dbg, sizeof(long long) * 32 * 512));
+        SG_CHECK(hipMemsetAsync(d->d_dbg, 0, sizeof(long long) * 32 * 512, d->ctx->stream)); SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    }
+    if (out && d->d_dbg) {
+        SG_REQUIRE(n_blocks <= 512, "sg_test_disc_phase_times: at most 512 blocks");
+        SG_COPY_SYNC(d->ctx, out, d->d_dbg, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost);   // n_blocks = 512: + k_disc_wgrad stamps
+    }
+    if (!enable && d->d_dbg) { SG_CHECK(hipFree(d->d_dbg)); d->d_dbg = nullptr; }
+    return 0;
+}
+
+// Test hook: per-phase shader-clock timestamps of k_ppo_fwd, row groups [0, n_blocks) (tools/ppo_phase_times.py).
+extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, int n_blocks) {
+    SG_REQUIRE(a, "sg_test_ppo_phase_times: NULL argument");
+    SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    if (enable && !a->d_dbg) {
+        SG_CHECK(hipMalloc((void**)&a->d_dbg, sizeof(long long) * 16 * 1024));
+        SG_CHECK(hipMemsetAsync(a->d_dbg, 0, sizeof(long long) * 16 * 1024, a->ctx->stream)); SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    }
+    if (out && a->d_dbg) {
+        SG_REQUIRE(n_blocks <= 1024, "sg_test_ppo_phase_times: at most 1024 blocks");
+        SG_COPY_SYNC(a->ctx, out, a->d_dbg, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost);
+    }
+    if (!enable && a->d_dbg) { SG_CHECK(hipFree(a->d_dbg)); a->d_dbg = nullptr; }
+    return 0;
+}
+
+// The permutation exactly as the product draws it (sg_ppo.hip:sg_fill_perm: key and round count come from sg_rng.hpp).
+__global__ void k_test_fill_perm(int64_t* perm, int64_t n, int half_bits, uint64_t key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = sg_perm_at(i, n, half_bits, key);
+}
+
+// Test hook: the library's counter-based generators as host arrays (tests/test_gpu_fullsize.py).
+// kind 0: random permutation of [0, n) -> int64 out;  1: uniform [0,1) -> float out;  2: normal -> float out.
+__global__ void k_test_rng(float* out, int64_t n, uint64_t seed, int kind) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = kind == 1 ? sg_uniform(seed, 7, (uint64_t)i) : sg_normal(seed, 7, (uint64_t)i);
+}
+
+extern "C" int sg_test_rng(sg_ctx* ctx, int kind, int64_t n, uint64_t seed, void* out) {
+    SG_REQUIRE(ctx && out && n > 0 && kind >= 0 && kind <= 2, "sg_test_rng: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    void* dev = nullptr;
+    SG_CHECK(hipMalloc(&dev, (size_t)n * 8));
+    if (kind == 0) {
+        hipLaunchKernelGGL(k_test_fill_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t*)dev, n,
+                           sg_perm_half_bits((uint64_t)n), sg_key(seed, 0x5045524Dull, 3));
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 8, hipMemcpyDeviceToHost);
+    } else {
+        hipLaunchKernelGGL(k_test_rng, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)dev, n, seed, kind);
+        SG_CHECK(hipStreamSynchronize(ctx->stream));
+        SG_COPY_SYNC(ctx, out, dev, (size_t)n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dev);
     return 0;
 }

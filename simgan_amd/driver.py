@@ -97,6 +97,26 @@ class ExpertLoader(object):
         self.batch_size = int(batch_size)
 
 
+class _ResidentRms(RunningMeanStd):
+    """`learner.ret_rms` while the state lives in the library (device-resident updates): a snapshot read from the device
+    when the attribute is accessed (one stream synchronisation per access), whose every mutation -- `set_state`, `update`,
+    `update_from_moments`, i.e. also a `relabel_rewards(..., learner.ret_rms)` call -- writes through to the device, so
+    nothing done to it in place is lost on the next access or update."""
+
+    def __init__(self, discr, state):
+        RunningMeanStd.__init__(self, shape=())
+        RunningMeanStd.set_state(self, state)
+        self._discr = discr
+
+    def set_state(self, st):
+        RunningMeanStd.set_state(self, st)
+        self._discr.set_rms(self.get_state())
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        RunningMeanStd.update_from_moments(self, batch_mean, batch_var, batch_count)
+        self._discr.set_rms(self.get_state())
+
+
 class GailDynLearner(object):
     def __init__(self, actor_critic, agent, discr, rollouts, expert, gail_batch_size=128, gail_epoch=5,
                  gamma=0.99, gae_lambda=0.95, use_gae=True, use_proper_time_limits=True,
@@ -117,7 +137,9 @@ class GailDynLearner(object):
     @property
     def ret_rms(self):
         if self._rms_on_device:
-            self._ret_rms.set_state(self.discr.scalars()[:3])
+            st = self.discr.scalars()[:3]
+            self._ret_rms.set_state(st)
+            return _ResidentRms(self.discr, st)     # mutations write through to the device
         return self._ret_rms
 
     @ret_rms.setter

@@ -9,7 +9,11 @@ from . import _lib
 from .utils import derive_seed, orthogonal, to_host_tensor
 
 
-MATERIALISE_CTX = None   # context for policies that build their device twin lazily (bare torch.load); None = Context.default()
+# Context for policies that build their device twin lazily (a bare torch.load of a reference checkpoint): None = the
+# process default (`Context.default()`, which `ctx.make_default()` re-points).  A process that holds several contexts
+# (loopback ranks on threads) assigns `simgan_amd.model.MATERIALISE_CTX = ctx` around its torch.load, or uses
+# `checkpoint.load_policy(path, ctx=ctx)`, which builds the policy on `ctx` directly and never comes through here.
+MATERIALISE_CTX = None
 
 
 class _PolicyBase(object):
@@ -52,8 +56,8 @@ class _PolicyBase(object):
         st = self.__dict__.pop("_pending")
         try:
             dims, sd = policy_from_module_state(type(self).__name__, st)
-            # the context an unpickled policy lands on: `simgan_amd.model.MATERIALISE_CTX` when the loader set one
-            # (checkpoint.load_policy(ctx=...)), the process default otherwise
+            # the context an unpickled policy lands on: `simgan_amd.model.MATERIALISE_CTX` when the caller set one,
+            # the process default otherwise (see the module-level comment)
             self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], MATERIALISE_CTX)
             self.seed = derive_seed(0, 0x5EED, per_instance=True)
             self.load_state_dict(sd)

@@ -23,12 +23,42 @@ def test_header_declares_the_expected_surface():
     assert len(syms) >= 45
 
 
+def exported_functions(path):
+    """Function symbols in the dynamic symbol table (`nm -D --defined-only`, type T)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[2] for line in out.splitlines() if len(line.split()) == 3 and line.split()[1] == "T")
+
+
 def test_library_exports_every_declared_symbol():
     from simgan_amd import _lib
     assert os.path.exists(_lib.LIB_PATH), "libsimgan_hip.so missing: run __graft_entry__.build()"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in include/simgan_hip.h but not exported: {missing}"
+
+
+def test_library_exports_nothing_but_the_header():
+    """-fvisibility=hidden + SG_API: the exported functions are exactly the header's declarations -- no internal helper, no
+    C++-mangled symbol, no test hook (those live in libsimgan_hip_test.so)."""
+    from simgan_amd import _lib
+    exported = exported_functions(_lib.LIB_PATH)
+    assert exported == declared_symbols(), (sorted(set(exported) - set(declared_symbols())), sorted(set(declared_symbols()) - set(exported)))
+    assert not [s for s in exported if s.startswith("sg_test_")]
+
+
+def test_test_library_exports_only_hooks_and_is_not_used_by_the_product():
+    from simgan_amd import _lib
+    assert os.path.exists(_lib.TEST_LIB_PATH), "libsimgan_hip_test.so missing: run __graft_entry__.build()"
+    exported = exported_functions(_lib.TEST_LIB_PATH)
+    assert exported == sorted(_lib.TEST_PROTOTYPES), (exported, sorted(_lib.TEST_PROTOTYPES))
+    pkg = os.path.join(ROOT, "simgan_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "load_test" not in src and "sg_test_" not in src, f"{f} uses the test hooks"
+    assert "load_test" not in open(os.path.join(ROOT, "bench.py")).read()
 
 
 def test_ctypes_prototypes_cover_the_header():

@@ -89,11 +89,9 @@ out = []
 for _ in range(2):                                    # second round replays the instantiated graphs
     out.append(disc.update_gail_dyn(Loader(expert, 128), ro))
     out.append(agent.update(ro))
-fn = lib.sg_test_graph_state
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, _lib.H, C.POINTER(C.c_int)]
+fn = _lib.load_test().sg_test_graph_state
 st = (C.c_int * 2)()
-_lib.check(fn(agent.h, disc.h, st))
+_lib.check_test(fn(agent.h, disc.h, st))
 np.savez(sys.argv[1], losses=np.array(out, np.float64), pi=pol.get_flat_params(), d=disc.get_flat_params(), state=np.array(list(st)))
 print("GRAPH-CHILD-OK")
 '''

@@ -163,33 +163,29 @@ def test_library_rng_and_determinism(world):
 def test_device_permutation_is_a_bijection(world, n):
     _lib, lib = world["_lib"], world["lib"]
     ctx = _lib.Context.default()
-    fn = lib.sg_test_rng
-    fn.restype = C.c_int
-    fn.argtypes = [_lib.H, C.c_int, C.c_int64, C.c_uint64, C.c_void_p]
+    fn = _lib.load_test().sg_test_rng
     perm = np.empty(n, np.int64)
-    _lib.check(fn(ctx.h, 0, n, 12345, perm.ctypes.data_as(C.c_void_p)))
+    _lib.check_test(fn(ctx.h, 0, n, 12345, perm.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(np.sort(perm), np.arange(n))
     if n >= 4096:   # not the identity, not a rotation: displacement statistics of a random permutation
         disp = np.abs(perm - np.arange(n)) / n
         assert 0.25 < disp.mean() < 0.42
         perm2 = np.empty(n, np.int64)
-        _lib.check(fn(ctx.h, 0, n, 12346, perm2.ctypes.data_as(C.c_void_p)))
+        _lib.check_test(fn(ctx.h, 0, n, 12346, perm2.ctypes.data_as(C.c_void_p)))
         assert (perm != perm2).mean() > 0.99
 
 
 def test_device_uniform_and_normal(world):
     _lib, lib = world["_lib"], world["lib"]
     ctx = _lib.Context.default()
-    fn = lib.sg_test_rng
-    fn.restype = C.c_int
-    fn.argtypes = [_lib.H, C.c_int, C.c_int64, C.c_uint64, C.c_void_p]
+    fn = _lib.load_test().sg_test_rng
     n = 1 << 20
     u = np.empty(n, np.float32)
-    _lib.check(fn(ctx.h, 1, n, 5, u.ctypes.data_as(C.c_void_p)))
+    _lib.check_test(fn(ctx.h, 1, n, 5, u.ctypes.data_as(C.c_void_p)))
     assert u.min() >= 0.0 and u.max() < 1.0
     assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3
     z = np.empty(n, np.float32)
-    _lib.check(fn(ctx.h, 2, n, 5, z.ctypes.data_as(C.c_void_p)))
+    _lib.check_test(fn(ctx.h, 2, n, 5, z.ctypes.data_as(C.c_void_p)))
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3 and np.isfinite(z).all()
     assert abs((np.abs(z) > 2).mean() - 0.0455) < 2e-3
 

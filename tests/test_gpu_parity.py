@@ -50,7 +50,7 @@ def test_gemm_engine(sg, mode, M, N, K):
         A, B = rng.standard_normal((K, M)), rng.standard_normal((K, N)); ref = 2.0 * (A.T @ B)
     A, B = A.astype(np.float32), B.astype(np.float32)
     Cm = np.zeros((M, N), np.float32)
-    _lib.check(ctx.lib.sg_test_gemm(ctx.h, mode, M, N, K, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cm)))
+    _lib.check_test(_lib.load_test().sg_test_gemm(ctx.h, mode, M, N, K, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cm)))
     assert_close(Cm, ref, rtol=1e-5, atol=1e-4, what=f"gemm mode {mode}")
 
 

@@ -10,11 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simgan_amd import _lib  # noqa: E402
 
-lib = _lib.load()
 ctx = _lib.Context.default()
-fn = lib.sg_test_fetch_probe
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+fn = _lib.load_test().sg_test_fetch_probe
 NL = 27
 print("blocks waves mode                       bytes/block   first pass: cycles (B/clk)    re-read from L2: cycles (B/clk)")
 for mode, name in ((0, "16-B loads, shared image"), (8, "same, nontemporal writer"), (1, "16-B loads, own copy/block"),
@@ -22,7 +19,7 @@ for mode, name in ((0, "16-B loads, shared image"), (8, "same, nontemporal write
     for waves in (7, 4, 1):
         for nb in (1, 8, 96, 256):
             buf = (C.c_longlong * (3 * nb))()
-            _lib.check(fn(ctx.h, nb, waves, mode, buf))
+            _lib.check_test(fn(ctx.h, nb, waves, mode, buf))
             t = np.array(buf, dtype=np.int64).reshape(nb, 3)
             nbytes = waves * NL * 1024 // (2 if mode == 4 else 1)
             f, w = np.median(t[:, 0]), np.median(t[:, 1])

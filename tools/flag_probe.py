@@ -7,16 +7,13 @@ import numpy as np
 sys.path.insert(0, ".")
 from simgan_amd import _lib  # noqa: E402
 
-lib = _lib.load()
 ctx = _lib.Context.default()
-fn = lib.sg_test_flag_probe
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_float)]
+fn = _lib.load_test().sg_test_flag_probe
 for mode, np_, nc, words in ((0, 96, 100, 2048), (1, 96, 100, 2048), (2, 96, 100, 2048), (2, 96, 100, 8192), (2, 32, 100, 2048), (0, 1, 8, 256), (1, 1, 8, 256), (2, 1, 8, 256),
                              (3, 1, 8, 256), (3, 16, 16, 2048), (3, 16, 16, 8192), (3, 24, 8, 8192), (2, 16, 16, 2048), (2, 16, 16, 8192)):
     st = (C.c_longlong * (2 * (np_ + nc)))()
     sums = (C.c_float * nc)()
-    _lib.check(fn(ctx.h, mode, np_, nc, words, st, sums))
+    _lib.check_test(fn(ctx.h, mode, np_, nc, words, st, sums))
     s = np.array(st, dtype=np.int64).reshape(-1, 2)
     p, c = s[:np_], s[np_:]
     expect = words * sum(range(1, np_ + 1))

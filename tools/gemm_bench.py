@@ -8,9 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simgan_amd import _lib  # noqa: E402
 
 ctx = _lib.Context.default()
-fn = ctx.lib.sg_test_gemm_bench
-fn.restype = C.c_int
-fn.argtypes = [_lib.H] + [C.c_int] * 7 + [C.POINTER(C.c_longlong)]
+fn = _lib.load_test().sg_test_gemm_bench
 ITERS = 200
 print("mode MT   K  Np thr epi | cycles/iter | MFMA-bound(cyc) | eff")
 for mode, MT, K, Np in [(0, 1, 112, 112), (0, 1, 96, 112), (0, 2, 112, 112), (0, 4, 64, 64), (1, 1, 112, 112),
@@ -18,7 +16,7 @@ for mode, MT, K, Np in [(0, 1, 112, 112), (0, 1, 96, 112), (0, 2, 112, 112), (0,
     for thr in (256, 512):
         for epi in ((0, 1) if mode == 0 else (0,)):
             cyc = C.c_longlong(0)
-            _lib.check(fn(ctx.h, mode, MT, K, Np, thr, ITERS, epi, C.byref(cyc)))
+            _lib.check_test(fn(ctx.h, mode, MT, K, Np, thr, ITERS, epi, C.byref(cyc)))
             per = cyc.value / ITERS
             if mode == 2:
                 mfma = (K // 16) * (Np // 16) * (16 * MT // 4)   # tiles x MFMAs (K index = rows R=16*MT)

@@ -15,16 +15,14 @@ w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "northstar"]
 pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, 0)
 lib = _lib.load()
 _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
-fn = lib.sg_test_disc_phase_times
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, C.c_int, C.POINTER(C.c_longlong), C.c_int]
+fn = _lib.load_test().sg_test_disc_phase_times
 disc.update_gail_dyn(loader, ro)  # warm
-_lib.check(fn(disc.h, 1, None, 0))
+_lib.check_test(fn(disc.h, 1, None, 0))
 disc.update_gail_dyn(loader, ro)
 thin = os.environ.get("SG_DISC_CHAIN", "thin") != "wide"
 nb = (12 if thin else 2) * ((w["B"] + 15) // 16)
 buf = (C.c_longlong * (32 * nb))()
-_lib.check(fn(disc.h, 1, buf, nb))
+_lib.check_test(fn(disc.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 32)
 for name, b in ((("mix block 0", 0), ("mix block 9", 9), ("BCE block", nb // 3 + 5)) if thin else (("BCE block 0", 0), ("mix block", nb // 2))):
     row = t[b]
@@ -34,7 +32,7 @@ for name, b in ((("mix block 0", 0), ("mix block 9", 9), ("BCE block", nb // 3 +
         print(f"   phase {i0:2d}->{i1:2d}: {row[i1] - row[i0]:8d} cycles")
 # wall-clock (100 MHz) timeline of the LAST step of the epoch: chain blocks, then k_disc_wgrad blocks by role
 full = (C.c_longlong * (32 * 512))()
-_lib.check(fn(disc.h, 1, full, 512))
+_lib.check_test(fn(disc.h, 1, full, 512))
 f = np.array(full, dtype=np.int64).reshape(512, 32)
 cs, ce = f[:nb, 28], f[:nb, 29]
 t0 = cs.min()
@@ -53,4 +51,4 @@ for nm, k in (("operands loaded + MFMA", 1), ("LDS reduce barrier", 2), ("Adam +
 sp = wg[(wg[:, 1] == 0) & (wg[:, 3] > 0)]
 if len(sp):
     print(f"wgrad Adam-scalar lane (double pow): done at +{10 * int((sp[:, 3] - sp[:, 0]).max())} ns")
-_lib.check(fn(disc.h, 0, None, 0))
+_lib.check_test(fn(disc.h, 0, None, 0))

@@ -15,10 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simgan_amd import _lib  # noqa: E402
 
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-lib = _lib.load()
 ctx = _lib.Context.default()
-fn = lib.sg_test_pmc_calibrate
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, C.c_int64]
-_lib.check(fn(ctx.h, mb))
+fn = _lib.load_test().sg_test_pmc_calibrate
+_lib.check_test(fn(ctx.h, mb))
 print(f"moved {mb} MiB per kernel")

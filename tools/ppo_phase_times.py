@@ -16,15 +16,13 @@ pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, 0)
 lib = _lib.load()
 _lib.check(lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
 _lib.check(lib.sg_rollout_compute_returns_policy(ro.h, pol.h, 1, 0.99, 0.95, 1))
-fn = lib.sg_test_ppo_phase_times
-fn.restype = C.c_int
-fn.argtypes = [_lib.H, C.c_int, C.POINTER(C.c_longlong), C.c_int]
+fn = _lib.load_test().sg_test_ppo_phase_times
 agent.update(ro)
-_lib.check(fn(agent.h, 1, None, 0))
+_lib.check_test(fn(agent.h, 1, None, 0))
 agent.update(ro)
 nb = 1024
 buf = (C.c_longlong * (16 * nb))()
-_lib.check(fn(agent.h, 1, buf, nb))
+_lib.check_test(fn(agent.h, 1, buf, nb))
 t = np.array(buf, dtype=np.int64).reshape(nb, 16)
 names = ["rows->LDS (fused bwd: until the weight commit)", "commit+sync", "L1", "L2", "head"]
 t1 = t[512:]
@@ -44,7 +42,7 @@ print("k_ppo_bwd phases (trunk 0), median cycles over", nb, "row groups:")
 for i, n in enumerate(names):
     print(f"   {n:12s} {int(np.median(d[:, i])):8d}   (min {int(d[:, i].min())}, max {int(d[:, i].max())})")
 print("   total       ", int(np.median(t[:, 15] - t[:, 8])))
-_lib.check(fn(agent.h, 0, None, 0))
+_lib.check_test(fn(agent.h, 0, None, 0))
 
 st, en = t[:, 6], t[:, 7]     # wall clock, 100 MHz, comparable across CUs
 ok = st > 0
