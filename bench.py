@@ -8,7 +8,7 @@ rollout (a2c/main_gail_dyn_ppo.py:255-302, a2c/ = third_party/a2c_ppo_acktr/):
 Inputs (rollout, expert matrix, weights, optimizer state) are resident in HBM before the timed
 region starts; nothing is skipped inside it.
 
-    python bench.py --gpus N --steps K --warmup W [--workload northstar|hopper|laikago|refine]
+    python bench.py --gpus N --steps K --warmup W [--workload northstar|hopper|laikago|refine|hopper_ppo]
 
 `--workload refine` is the plain-PPO caller (a2c/main.py:199-257, BASELINE.json configs[4]: Laikago policy refinement,
 2048 envs -> 256 per GPU, obs 111, 8 minibatches, clip 0.1, lr 1.5e-4 with linear decay): no discriminator, one step =
@@ -48,6 +48,11 @@ WORKLOADS = {
     # BASELINE.json configs[4]: Laikago policy refinement (train_laika_power.sh:7), main.py caller, no discriminator
     "refine": dict(kind="mlp", T=128, N=256, O=111, A=12, F=111, H=64, feet=1, Hd=100, E_p=10, M=8, E_d=0,
                    B=128, Ne=0, clip=0.1, lr=1.5e-4),
+    # BASELINE.json configs[0]: HopperURDFEnv-v3 plain PPO at the reference's own CPU-runnable geometry (a2c/main.py with the
+    # defaults of a2c/arguments.py: 8 processes x 128 steps, 32 minibatches -> 32-ROW optimizer steps, 320 per update, entropy
+    # coefficient 0.01, no LR decay): the smallest grid k_ppo_bwd ever runs on (one workgroup per trunk)
+    "hopper_ppo": dict(kind="mlp", T=128, N=8, O=11, A=3, F=11, H=64, feet=1, Hd=100, E_p=10, M=32, E_d=0,
+                       B=128, Ne=0, clip=0.2, lr=3e-4, ecoef=0.01, lr_decay=False),
 }
 GAMMA, LAM = 0.99, 0.95
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -122,11 +127,11 @@ def build_problem(sg, w, seed):
         pol = sg.Policy((w["O"],), Box((w["A"],)), base_kwargs={"recurrent": False, "hidden_size": w["H"]}, seed=seed)
     else:
         pol = sg.SplitPolicy((w["O"],), Box((w["A"],)), base_kwargs={"hidden_size": w["H"], "num_feet": w["feet"]}, seed=seed)
-    agent = sg.algo.PPO(pol, w["clip"], w["E_p"], w["M"], 0.5, 0.0, lr=lr, eps=1e-5, max_grad_norm=0.5)
+    agent = sg.algo.PPO(pol, w["clip"], w["E_p"], w["M"], 0.5, w.get("ecoef", 0.0), lr=lr, eps=1e-5, max_grad_norm=0.5)
     ro = sg.RolloutStorage(w["T"], w["N"], (w["O"],), Box((w["A"],)), 1, w["F"])
     ro.device_resident = True
     if not w["E_d"]:   # a2c/main.py: PPO only, linear LR decay over the run's updates (train_laika_power.sh:7)
-        learner = PpoLearner(pol, agent, ro, gamma=GAMMA, gae_lambda=LAM, use_linear_lr_decay=True, lr=lr, num_updates=1000)
+        learner = PpoLearner(pol, agent, ro, gamma=GAMMA, gae_lambda=LAM, use_linear_lr_decay=w.get("lr_decay", True), lr=lr, num_updates=1000)
         return pol, None, agent, ro, None, None, learner
     disc = sg.algo.gail.Discriminator(w["F"], w["Hd"], None, seed=seed)
     expert = rng.standard_normal((w["Ne"], w["F"])).astype(np.float32)   # identical on every rank (same seed)
@@ -163,7 +168,7 @@ def cpu_baseline(w, expert, budget_s):
     obs = rng.standard_normal((mb, O)).astype(np.float32)
     act = rng.standard_normal((mb, A)).astype(np.float32)
     z = rng.standard_normal((4, mb)).astype(np.float32)
-    cfg = orc.ppo_cfg(w["clip"], 1, 1, 0.5, 0.0, w.get("lr", 3e-4), 1e-5, 0.5, True)
+    cfg = orc.ppo_cfg(w["clip"], 1, 1, 0.5, w.get("ecoef", 0.0), w.get("lr", 3e-4), 1e-5, 0.5, True)
     rows = np.arange(mb)
     x = rng.standard_normal((2048, F)).astype(np.float32)
     if w["E_d"]:
@@ -368,7 +373,7 @@ def main():
                            "algorithmic_bytes": kbytes, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
                            "traffic": counter_traffic(kname)}
         out = {
-            "metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else "env-steps/sec of PPO update (policy refinement, a2c/main.py)", "value": round(value, 1), "unit": "env-steps/s",
+            "metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else ("env-steps/sec of PPO update (policy refinement, a2c/main.py)" if args.workload == "refine" else "env-steps/sec of PPO update (a2c/main.py)"), "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.workload}: GAIL-dyn update, T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
@@ -376,7 +381,7 @@ def main():
                                     f"num_mini_batch={w['M']} gail_epoch={w['E_d']} gail_batch={w['B']} expert_rows={w['Ne']}") if w["E_d"] else
                                    (f"{args.workload}: PPO update (a2c/main.py caller), T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
                                     f"policy={w['kind']} h{w['H']} ppo_epoch={w['E_p']} num_mini_batch={w['M']} clip={w['clip']} "
-                                    f"lr={w['lr']} linear decay"),
+                                    f"entropy_coef={w.get('ecoef', 0.0)} lr={w['lr']}{' linear decay' if w.get('lr_decay', True) else ''}"),
                        "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
                        "parallelism": f"dp{world} (env columns sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom_kernel, "achieved": round(achieved, 3),
