@@ -48,6 +48,41 @@ def lib():
     return _LIB
 
 
+_FAST = {}
+
+
+def build_fast_native():
+    """bench.py's cpu_baseline leg: compile sg_cpu_fast.c for THE HOST IT IS TIMED ON (-march=native) into a scratch
+    directory.  Returns the path, or None when that fails (the in-tree x86-64-v3 build is used then)."""
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="sg_cpu_fast_"), "libsg_cpu_fast_native.so")
+    cmd = ["gcc", "-O3", "-fPIC", "-std=gnu99", "-ffast-math", "-march=native", "-fopenmp", "-shared", "-o", out,
+           os.path.join(_HERE, "sg_cpu_fast.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return out
+    except (OSError, subprocess.CalledProcessError):
+        return None
+
+
+def fast_lib(native=False):
+    """oracle/sg_cpu_fast.c: the batched, vectorised CPU implementation bench.py times as `cpu_baseline` (parity-checked
+    against the oracle in tests/test_oracle_golden.py; never the checker itself)."""
+    key = "native" if native else "v3"
+    if key not in _FAST:
+        so = build_fast_native() if native else None
+        if so is None:
+            so = os.path.join(_HERE, "libsg_cpu_fast.so")
+            src = os.path.join(_HERE, "sg_cpu_fast.c")
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, "-B", "libsg_cpu_fast.so"], stdout=subprocess.DEVNULL)
+            key2 = "v3"
+        else:
+            key2 = "native"
+        _FAST[key] = (C.CDLL(so), key2)
+    return _FAST[key]
+
+
 def _f(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
@@ -164,6 +199,36 @@ def ppo_grad_rows(d, params, cfg, obs, actions, value_preds, returns, old_logp, 
     sums = (C.c_double * 3)(0, 0, 0)
     lib().orc_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
                             int(rows.size), C.c_float(inv_B), _fp(G), sums)
+    return G, np.array(list(sums))
+
+
+def ppo_grad_rows_fast(d, params, cfg, obs, actions, value_preds, returns, old_logp, adv, rows, inv_B, native=False):
+    """oracle/sg_cpu_fast.c:fast_ppo_grad_rows -- same contract as ppo_grad_rows, batched GEMMs."""
+    params, pp = _f(params)
+    obs, po = _f(obs)
+    actions, pa = _f(actions)
+    value_preds, pv = _f(value_preds)
+    returns, pr = _f(returns)
+    old_logp, pl = _f(old_logp)
+    adv, pad = _f(adv)
+    rows, prow = _i64(rows)
+    G = np.zeros(params.size, np.float32)
+    sums = (C.c_double * 3)(0, 0, 0)
+    fast_lib(native)[0].fast_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
+                                           int(rows.size), C.c_float(inv_B), _fp(G), sums)
+    return G, np.array(list(sums))
+
+
+def disc_grad_rows_fast(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda_=10.0, native=False):
+    """oracle/sg_cpu_fast.c:fast_disc_grad_rows -- same contract as disc_grad_rows, batched GEMMs."""
+    params, pp = _f(params)
+    expert_rows, pe = _f(expert_rows)
+    policy_rows, ppol = _f(policy_rows)
+    alpha, pal = _f(alpha)
+    nb = expert_rows.shape[0]
+    G = np.zeros(params.size, np.float32)
+    sums = (C.c_double * 3)(0, 0, 0)
+    fast_lib(native)[0].fast_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums)
     return G, np.array(list(sums))
 
 

@@ -77,6 +77,10 @@ SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet);
 int64_t sg_policy_flat_count(const SgPolicyDesc& d);
 void sg_policy_pad(const SgPolicyDesc& d, const float* flat, float* padded);    // padded must be zeroed
 void sg_policy_unpad(const SgPolicyDesc& d, const float* padded, float* flat);
+struct sg_ctx;
+// true: the policy's trunks do not fit a CU's LDS beside a row tile (or SG_POLICY_GW=1): the forward / PPO kernels run
+// their global-weight instances (sg_policy.hip)
+bool sg_policy_needs_gw(const sg_ctx* ctx, const SgPolicyDesc& d);
 SgDiscDesc sg_make_disc_desc(int F, int Hd);
 int64_t sg_disc_flat_count(const SgDiscDesc& d);
 void sg_disc_pad(const SgDiscDesc& d, const float* flat, float* padded);

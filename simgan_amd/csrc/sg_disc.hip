@@ -43,9 +43,17 @@ int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_
 
 // shape-specialised instances: north-star / Laikago (F 86, Hd 100), Hopper (F 25, Hd 100), the
 // tiny test shape, and the run-time-shape fallback
-static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a) {
+// The LDS-resident chain / forward kernels need the whole parameter image beside their activation tiles; a larger
+// discriminator takes the global-weight instances (SG_DISC_GW=1 forces them for any shape: tests).
+static bool disc_needs_gw(const sg_ctx* ctx, const SgDiscDesc& dd) {
+    const char* e = getenv("SG_DISC_GW");
+    if (e && e[0] == '1') return true;
+    return disc_chain_lds_bytes(dd) > (size_t)ctx->lds_bytes;
+}
+static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size_t lds, const DiscArgs& a, bool gw) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     const dim3 block(SG_DISC_THREADS);
+    if (gw) { SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<0, 0, true>), grid, block, lds, a); return; }
     if (kf == 6 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<6, 7>), grid, block, lds, a);
     else if (kf == 2 && kh == 7) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<2, 7>), grid, block, lds, a);
     else if (kf == 1 && kh == 1) SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain<1, 1>), grid, block, lds, a);
@@ -54,9 +62,10 @@ static void launch_disc_chain(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, size
 
 // The 4-row kernel exists for the shipped shapes (everything in it is a compile-time extent);
 // other shapes, or SG_DISC_CHAIN=wide, take the 16-row kernel above.
-static bool disc_chain_thin(const SgDiscDesc& dd) {
+static bool disc_chain_thin(const sg_ctx* ctx, const SgDiscDesc& dd) {
     const char* e = getenv("SG_DISC_CHAIN");
     if (e && !strcmp(e, "wide")) return false;
+    if (disc_needs_gw(ctx, dd)) return false;
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     return (kf == 6 && kh == 7) || (kf == 2 && kh == 7) || (kf == 1 && kh == 1);
 }
@@ -93,23 +102,24 @@ struct DiscFwdArgs {
     int prob;
 };
 
-static size_t disc_fwd_lds_bytes(const SgDiscDesc& d) {
-    return sizeof(float) * ((size_t)d.total + 32 * d.ldF + 2 * 32 * d.ldH);
+static size_t disc_fwd_lds_bytes(const SgDiscDesc& d, bool gw = false) {
+    return sizeof(float) * ((gw ? 0 : (size_t)d.total) + 32 * d.ldF + 2 * 32 * d.ldH);
 }
 
+template <bool GW>
 __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 32;
     const SgDiscDesc& d = a.d;
     const int tid = threadIdx.x, ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp;
-    float* W = smem;
-    float* X = W + d.total;
+    const float* W = GW ? a.params : smem;
+    float* X = smem + (GW ? 0 : d.total);
     float* H1 = X + R * ldF;
     float* H2 = H1 + R * ldH;
     const float* b1 = W + d.b1;
     const float* b2 = W + d.b2;
     const float* w3 = W + d.w3;
-    sg_stage(W, a.params, d.total / 4);
+    if (!GW) sg_stage(smem, a.params, d.total / 4);
     const float offset = a.neg_offset_dev ? -(float)(*a.neg_offset_dev) : a.offset;
     for (int base = blockIdx.x * R; base < a.n; base += gridDim.x * R) {
         __syncthreads();
@@ -133,9 +143,9 @@ __global__ __launch_bounds__(256) void k_disc_forward(DiscFwdArgs a) {
             }
         }
         __syncthreads();
-        sg_layer_nt<2>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        sg_layer_nt<2, GW>(X, ldF, W + d.w1, ldF, Fp, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         __syncthreads();
-        sg_layer_nt<2>(H1, ldH, W + d.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        sg_layer_nt<2, GW>(H1, ldH, W + d.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
         const int r = tid >> 3, sub = tid & 7;
         float s = 0.f;
@@ -239,9 +249,12 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     sg_disc* d = new sg_disc();
     d->ctx = ctx;
     d->desc = sg_make_disc_desc(input_dim, hidden_dim);
-    SG_REQUIRE(disc_chain_lds_bytes(d->desc) <= (size_t)ctx->lds_bytes,
-               "sg_disc_create: discriminator (%d x %d) needs %zu bytes of LDS, the CU has %d", input_dim, hidden_dim,
-               disc_chain_lds_bytes(d->desc), ctx->lds_bytes);
+    // any (input_dim, hidden_dim) the reference's constructor accepts (a2c/algo/gail.py:40-43): a parameter image that fits a
+    // CU's LDS runs on the LDS-resident kernels, a larger one on the global-weight instances; only the activation tiles
+    // of a 16-row block have to fit
+    SG_REQUIRE(disc_chain_lds_bytes(d->desc, true) <= (size_t)ctx->lds_bytes,
+               "sg_disc_create: the activation tiles of a (%d x %d) discriminator need %zu bytes of LDS, the CU has %d", input_dim,
+               hidden_dim, disc_chain_lds_bytes(d->desc, true), ctx->lds_bytes);
     const size_t tot = d->desc.total;
     SG_CHECK(hipMalloc((void**)&d->d_params, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_m, sizeof(float) * tot));
@@ -493,7 +506,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
 
     const int G = (B_loc + 15) / 16;
     // scratch of one step: operand stacks | per-workgroup vector partials | (data-parallel) flat gradient
-    const bool thin = disc_chain_thin(dd);
+    const bool thin = disc_chain_thin(ctx, dd);
+    const bool gw = disc_needs_gw(ctx, dd);
     const int n_chain_wg = thin ? 12 * G : 2 * G;
     const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
@@ -521,7 +535,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     wa.grad_out = sharded ? grad : nullptr; wa.st = a.st; wa.eps = 1e-8f; wa.inv_B = a.inv_B; wa.lambda_ = a.lambda_;
     wa.loss_acc = d->d_loss_acc;
     wa.nparts = n_chain_wg; wa.wT = d->d_wT; wa.dbg = d->d_dbg;
-    const size_t lds = disc_chain_lds_bytes(dd);
+    const size_t lds = disc_chain_lds_bytes(dd, gw);
     const int n_tiles = (dd.Hp / 16) * (dd.Hp / 16) + (dd.Hp / 16) * (dd.Fp / 16);
     const int nblk = (dd.total + 255) / 256;
     const int n_vec = (3 * dd.Hp + 4 + 63) / 64;
@@ -574,7 +588,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
             wa.next = pg;
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
-            else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a);
+            else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a, gw);
             SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa.ops, wa.params, wa.m,
                       wa.v, wa.st, wa.G, dd.Hp, dd.Fp, (wa.xcd_map ? 1 : 0) | (wa.grad_out ? 2 : 0) | (wa.dbg ? 4 : 0), wa);
             if (sharded) {
@@ -596,7 +610,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
                                   (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size,
-                                  (uint64_t)thin | (sharded ? 2u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
+                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
@@ -660,7 +674,9 @@ static int disc_forward_dev(sg_disc* d, const float* d_x, int n, float offset, f
     f.neg_offset_dev = neg_offset_dev;
     int grid = (n + 31) / 32;
     if (grid > 2 * ctx->num_cu) grid = 2 * ctx->num_cu;
-    SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), f);
+    const bool gw = disc_needs_gw(ctx, d->desc) || disc_fwd_lds_bytes(d->desc) > (size_t)ctx->lds_bytes;
+    if (gw) SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward<true>, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc, true), f);
+    else SG_LAUNCH(ctx, SG_PROF_RELABEL, k_disc_forward<false>, dim3(grid), dim3(256), disc_fwd_lds_bytes(d->desc), f);
     SG_CHECK(hipGetLastError());
     return 0;
 }

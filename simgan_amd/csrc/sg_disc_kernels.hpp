@@ -82,10 +82,11 @@ __host__ __device__ __forceinline__ SgStacks sg_disc_stacks(float* ops, int Kt, 
     return k;
 }
 
-static size_t disc_chain_lds_bytes(const SgDiscDesc& d) {
+// gw: the global-weight instance (k_disc_chain<0, 0, true>): LDS holds the activation tiles only
+static size_t disc_chain_lds_bytes(const SgDiscDesc& d, bool gw = false) {
     const size_t bce = (size_t)32 * d.ldF + 2 * 32 * d.ldH + 64;
     const size_t mix = (size_t)2 * 16 * d.ldF + 7 * 16 * d.ldH + 64;
-    return sizeof(float) * ((size_t)d.total + (bce > mix ? bce : mix));
+    return sizeof(float) * ((gw ? 0 : (size_t)d.total) + (bce > mix ? bce : mix));
 }
 static size_t disc_ops_floats(const SgDiscDesc& d, int G) {
     const size_t Kt = (size_t)64 * G;
@@ -182,7 +183,10 @@ __global__ __launch_bounds__(512) void k_disc_pregather(PregatherArgs p) {
 // descriptor at run time): with the shape fixed, every GEMM extent, LDS offset and staging trip
 // count folds to a constant and the K/N dispatch switches of the tile engine collapse to the one
 // body needed (the kernel has to stay resident in the 64 KB instruction cache).
-template <int KF, int KH>
+// GW = true (run-time extents only): the parameter vector is NOT staged -- the layer GEMMs read W1 / W2 from global memory
+// (sg_gemm.hpp, "GW"), so any (input_dim, hidden_dim) the reference's constructor accepts runs (a2c/algo/gail.py:40-43,
+// --gail-dis-hdim a2c/arguments.py:212-215), as long as the 16- / 32-row activation tiles fit a CU's LDS.
+template <int KF, int KH, bool GW = false>
 __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     SgDiscDesc d = a.d;
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
     }
     const int tid = threadIdx.x;
     const int ldF = d.ldF, ldH = d.ldH, Fp = d.Fp, Hp = d.Hp;
-    float* W = smem;
+    const float* W = GW ? a.params : smem;
     const float* W1 = W + d.w1;
     const float* b1 = W + d.b1;
     const float* W2 = W + d.w2;
     const float* b2 = W + d.b2;
     const float* w3 = W + d.w3;
-    float* buf = W + d.total;
+    float* buf = smem + (GW ? 0 : d.total);
     const int nb = 16 * a.G, Kt = 4 * nb;
     const SgStacks stk = sg_disc_stacks(a.ops, Kt, Hp, Fp, ldF);
     float* L2s = stk.L2;
@@ -223,22 +227,22 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
         float* LOSS = DD + R;
         // parameter image: loads issued now (12 x 16 B per lane), committed to LDS after the row gather
         float4 wv[12];
-        sg_stage_issue<12>(wv, a.params, d.total / 4);
+        if (!GW) sg_stage_issue<12>(wv, a.params, d.total / 4);
         // this workgroup's 32 input rows were gathered into the right stack by the previous launch
         // (sg_disc_pregather): contiguous 16 B loads, no index indirection on the critical path
         for (int i = tid; i < R * (Fp / 4); i += blockDim.x) {
             const int r = i / (Fp / 4), c = 4 * (i % (Fp / 4));
             *reinterpret_cast<float4*>(X + r * ldF + c) = *reinterpret_cast<const float4*>(R1s + (size_t)(row0 + r) * ldF + c);
         }
-        sg_stage_commit<12>(W, wv, a.params, d.total / 4);
+        if (!GW) sg_stage_commit<12>(smem, wv, a.params, d.total / 4);
         SG_PHASE_SYNC(1);
-        sg_layer_nt<2>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
+        sg_layer_nt<2, GW>(X, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
             const float h = sg_tanh(v + b1[c]);
             H1[r * ldH + c] = h;
             R2s[SG_STK(Kt, row0 + r, c)] = h;
         });
         SG_PHASE_SYNC(2);
-        sg_layer_nt<2>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        sg_layer_nt<2, GW>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         SG_PHASE_SYNC(3);
         {   // logits, BCE losses and dL/dd: blockDim/32 lanes per row   (a2c/algo/gail.py:168-176)
             const int L = blockDim.x / R, r = tid / L, sub = tid % L;
@@ -313,20 +317,20 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
         float* Z2B = BU1 + R * ldH; // z2b
         float* ROWL = Z2B + R * ldH;
         float4 wv[12];
-        sg_stage_issue<12>(wv, a.params, d.total / 4);
+        if (!GW) sg_stage_issue<12>(wv, a.params, d.total / 4);
         for (int i = tid; i < R * (Fp / 4); i += blockDim.x) {   // pre-gathered mixup rows (see above)
             const int r = i / (Fp / 4), c = 4 * (i % (Fp / 4));
             *reinterpret_cast<float4*>(XM + r * ldF + c) = *reinterpret_cast<const float4*>(R1s + (size_t)(rowB + r) * ldF + c);
         }
-        sg_stage_commit<12>(W, wv, a.params, d.total / 4);
+        if (!GW) sg_stage_commit<12>(smem, wv, a.params, d.total / 4);
         SG_PHASE_SYNC(8);
-        sg_layer_nt<1>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
+        sg_layer_nt<1, GW>(XM, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {
             const float h = sg_tanh(v + b1[c]);
             H1[r * ldH + c] = h;
             R2s[SG_STK(Kt, rowB + r, c)] = h;
         });
         SG_PHASE_SYNC(9);
-        sg_layer_nt<1>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
+        sg_layer_nt<1, GW>(H1, ldH, W2, ldH, Hp, Hp, [&](int r, int c, float v) {
             const float h = sg_tanh(v + b2[c]);
             const float d2 = w3[c] * (1.f - h * h);
             H2[r * ldH + c] = h;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             if (sub == 0) ROWL[r] = valid ? (nn - 1.f) * (nn - 1.f) : 0.f;
         }
         SG_PHASE_SYNC(13);
-        sg_layer_nt<1>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {      // bd1 = gb W1^T
+        sg_layer_nt<1, GW>(GX, ldF, W1, ldF, Fp, Hp, [&](int r, int c, float v) {      // bd1 = gb W1^T
             const float h = H1[r * ldH + c];
             const float bu1 = v * (1.f - h * h);
             BU1[r * ldH + c] = bu1;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(SG_DISC_THREADS) void k_disc_chain(DiscArgs a) {
             U1[r * ldH + c] = v * U1[r * ldH + c];                                  // sb1 = bd1*u1
         });
         SG_PHASE_SYNC(14);
-        sg_layer_nt_t<1>(BU1, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // bd2 = bu1 W2^T
+        sg_layer_nt_t<1, GW>(BU1, ldH, W2, ldH, Hp, Hp, [&](int tn, f32x4 (&acc)[1][1]) {  // bd2 = bu1 W2^T
             const int c = tn * 16 + li;
             const float w = w3[c];
             float t3[1][4], z[1][4];

@@ -134,6 +134,55 @@ __device__ __forceinline__ void sg_mma_nt(const float* A, int lda, const float* 
     if (MT * NT == 1) acc[0][0] += alt;
 }
 
+// ---- NT, B operand in GLOBAL memory ("GW": weights read straight from L2 instead of an LDS-resident parameter image --
+// the general-shape path for networks whose parameter block does not fit a CU's 160 KB of LDS, sg_policy.hip /
+// sg_ppo.hip / sg_disc.hip).  Same contract as sg_mma_nt.  Reduction indices k = 16c + 4q + s (s = 0..3) for BOTH operands:
+// A (LDS, K-contiguous) is one ds_read_b128 per chunk, B one 16-byte global load per chunk (rows are 16-byte aligned:
+// ld is a multiple of 4); all loads of a K block are issued before its first MFMA.  NN with a global B needs no twin:
+// sg_mma_nn reads B through plain pointers.
+template <int MT, int NT, int KC>
+__device__ __forceinline__ void sg_mma_nt_g_blk(const float*& ap, int lda, const float*& bp, int ldb,
+                                                f32x4 (&acc)[MT][NT], f32x4& alt) {
+    constexpr bool DUAL = (MT * NT == 1);
+    float4 a[KC][MT], b[KC][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[c][j] = *reinterpret_cast<const float4*>(bp + (size_t)j * 16 * ldb + 16 * c);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[c][i] = *reinterpret_cast<const float4*>(ap + i * 16 * lda + 16 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float av = s == 0 ? a[c][i].x : s == 1 ? a[c][i].y : s == 2 ? a[c][i].z : a[c][i].w;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float bv = s == 0 ? b[c][j].x : s == 1 ? b[c][j].y : s == 2 ? b[c][j].z : b[c][j].w;
+                    if (DUAL && (s & 1)) alt = sg_mfma(av, bv, alt);
+                    else acc[i][j] = sg_mfma(av, bv, acc[i][j]);
+                }
+            }
+    ap += 16 * KC;
+    bp += 16 * KC;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void sg_mma_nt_g(const float* A, int lda, const float* B, int ldb, int K,
+                                            f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const float* ap = A + li * lda + 4 * lq;
+    const float* bp = B + (size_t)li * ldb + 4 * lq;
+    f32x4 alt = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SG_BODY(N) sg_mma_nt_g_blk<MT, NT, N>(ap, lda, bp, ldb, acc, alt)
+    SG_KC_DISPATCH(K >> 4, SG_BODY);
+#undef SG_BODY
+    if (MT * NT == 1) acc[0][0] += alt;
+}
+
 // ---- NN:  C[m][n] += sum_k A[m][k] * B[k][n].  A -> row m0 of [.][lda]; B -> column n0 of [K][ldb].
 // (dY x W: back-propagation through nn.Linear to its input)
 template <int MT, int NT, int KC>
@@ -251,14 +300,16 @@ __device__ __forceinline__ float sg_tile_colsum(const float (&v)[MT][4]) {
 // The *_t variants hand the epilogue a whole column block: ep(tn, acc[MT][1]).
 // ---------------------------------------------------------------------------------------------
 
-template <int MT, typename EP>
+// GW = true: W points into global memory (sg_mma_nt_g); the NN forms read W through plain pointers either way.
+template <int MT, bool GW = false, typename EP>
 __device__ __forceinline__ void sg_layer_nt_t(const float* in, int ldi, const float* W, int ldw,
                                               int K, int Np, EP&& ep) {
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int tn = wave; tn * 16 < Np; tn += nw) {
         f32x4 acc[MT][1];
         sg_acc_zero(acc);
-        sg_mma_nt<MT, 1>(in, ldi, W + tn * 16 * ldw, ldw, K, acc);
+        if (GW) sg_mma_nt_g<MT, 1>(in, ldi, W + (size_t)tn * 16 * ldw, ldw, K, acc);
+        else sg_mma_nt<MT, 1>(in, ldi, W + tn * 16 * ldw, ldw, K, acc);
         ep(tn, acc);
     }
 }
@@ -276,10 +327,10 @@ __device__ __forceinline__ void sg_layer_nn_t(const float* dY, int ldy, const fl
 }
 
 // out[r][c] = ep(r, c, sum_k in[r][k] * W[c][k])  for c < Np   (forward layer / "NT")
-template <int MT, typename EP>
+template <int MT, bool GW = false, typename EP>
 __device__ __forceinline__ void sg_layer_nt(const float* in, int ldi, const float* W, int ldw,
                                             int K, int Np, EP&& ep) {
-    sg_layer_nt_t<MT>(in, ldi, W, ldw, K, Np, [&](int tn, f32x4 (&acc)[MT][1]) {
+    sg_layer_nt_t<MT, GW>(in, ldi, W, ldw, K, Np, [&](int tn, f32x4 (&acc)[MT][1]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) sg_tile_foreach(acc[i][0], i * 16, tn * 16, ep);
     });
@@ -297,14 +348,15 @@ __device__ __forceinline__ void sg_layer_nn(const float* dY, int ldy, const floa
 
 // Unit-distributed forms: a task is ONE 16x16 output tile (row tile i, column tile tn), dealt round-robin to the waves.
 // With 8 waves and 32 rows x 64 columns every wave gets one tile (half the MFMA chain of the column-strip forms above).
-template <int MT, typename EP>
+template <int MT, bool GW = false, typename EP>
 __device__ __forceinline__ void sg_layer_nt_u(const float* in, int ldi, const float* W, int ldw, int K, int Np, EP&& ep) {
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, ntl = Np >> 4;
     for (int u = wave; u < MT * ntl; u += nw) {
         const int i = u / ntl, tn = u - i * ntl;
         f32x4 acc[1][1];
         sg_acc_zero(acc);
-        sg_mma_nt<1, 1>(in + i * 16 * ldi, ldi, W + tn * 16 * ldw, ldw, K, acc);
+        if (GW) sg_mma_nt_g<1, 1>(in + i * 16 * ldi, ldi, W + (size_t)tn * 16 * ldw, ldw, K, acc);
+        else sg_mma_nt<1, 1>(in + i * 16 * ldi, ldi, W + tn * 16 * ldw, ldw, K, acc);
         sg_tile_foreach(acc[0][0], i * 16, tn * 16, ep);
     }
 }

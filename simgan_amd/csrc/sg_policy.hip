@@ -30,8 +30,10 @@ struct FwdArgs {
     int wbuf_floats;
 };
 
-// One trunk forward on R = 16*MT rows held in LDS.  W = the trunk's parameter block in LDS.
-template <int MT>
+// One trunk forward on R = 16*MT rows held in LDS.  W = the trunk's parameter block: its LDS image, or (GW) the block in
+// global memory itself -- the general-shape path for trunks that do not fit a CU's LDS (any hidden size the reference's
+// --hidden-size accepts, a2c/arguments.py:107-109; weights come through L2 one MFMA fragment at a time, sg_gemm.hpp).
+template <int MT, bool GW = false>
 __device__ __forceinline__ void trunk_forward(const SgPolicyDesc& d, const SgTrunk& tr, const float* W,
                                               const float* X, float* H1, float* H2, float* OUT,
                                               int ldP) {
@@ -39,29 +41,29 @@ __device__ __forceinline__ void trunk_forward(const SgPolicyDesc& d, const SgTru
     const float* b1 = W + tr.b1;
     const float* b2 = W + tr.b2;
     const float* bh = W + tr.bh;
-    sg_layer_nt<MT>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp,
-                    [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+    sg_layer_nt<MT, GW>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp,
+                        [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
     __syncthreads();
-    sg_layer_nt<MT>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp,
-                    [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+    sg_layer_nt<MT, GW>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp,
+                        [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
     __syncthreads();
-    sg_layer_nt<MT>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp,
-                    [&](int r, int c, float v) { OUT[r * ldP + c] = v + bh[c]; });
+    sg_layer_nt<MT, GW>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp,
+                        [&](int r, int c, float v) { OUT[r * ldP + c] = v + bh[c]; });
 }
 
-template <int MT>
+template <int MT, bool GW = false>
 __global__ __launch_bounds__(256) void k_policy_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
     const SgPolicyDesc& d = a.d;
     const SgTrunk tr = d.trunk[blockIdx.y];
-    float* W = smem;
-    float* X = W + a.wbuf_floats;
+    const float* W = GW ? a.params + tr.off : smem;
+    float* X = smem + (GW ? 0 : a.wbuf_floats);
     float* H1 = X + R * d.ldO;
     float* H2 = H1 + R * d.ldH;
     float* OUT = H2 + R * d.ldH;
     const int ldP = tr.ldP;
-    sg_stage(W, a.params + tr.off, tr.size / 4);
+    if (!GW) sg_stage(smem, a.params + tr.off, tr.size / 4);
     float* heads = a.heads + (size_t)blockIdx.y * a.n * a.hld;
     for (int base = blockIdx.x * R; base < a.n; base += gridDim.x * R) {
         __syncthreads();
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_policy_forward(FwdArgs a) {
             X[r * d.ldO + c] = v;
         }
         __syncthreads();
-        trunk_forward<MT>(d, tr, W, X, H1, H2, OUT, ldP);
+        trunk_forward<MT, GW>(d, tr, W, X, H1, H2, OUT, ldP);
         __syncthreads();
         for (int i = threadIdx.x; i < R * tr.Pp; i += blockDim.x) {
             const int r = i / tr.Pp, c = i - r * tr.Pp;
@@ -151,9 +153,16 @@ static int max_ldP(const SgPolicyDesc& d) {
     for (int t = 0; t < d.n_trunks; ++t) m = d.trunk[t].ldP > m ? d.trunk[t].ldP : m;
     return m;
 }
-static size_t fwd_lds_bytes(const SgPolicyDesc& d, int MT) {
+static size_t fwd_lds_bytes(const SgPolicyDesc& d, int MT, bool gw = false) {
     const int R = 16 * MT;
-    return sizeof(float) * (size_t)(max_trunk_size(d, 0, d.n_trunks) + R * d.ldO + 2 * R * d.ldH + R * max_ldP(d));
+    return sizeof(float) * (size_t)((gw ? 0 : max_trunk_size(d, 0, d.n_trunks)) + R * d.ldO + 2 * R * d.ldH + R * max_ldP(d));
+}
+// The LDS-resident kernels need a trunk's whole parameter block beside one 16-row tile; a policy that does not fit takes
+// the global-weight instances (SG_POLICY_GW=1 forces them for any shape: tests).
+bool sg_policy_needs_gw(const sg_ctx* ctx, const SgPolicyDesc& d) {
+    const char* e = getenv("SG_POLICY_GW");
+    if (e && e[0] == '1') return true;
+    return fwd_lds_bytes(d, 1) > (size_t)ctx->lds_bytes - 1024;
 }
 
 // Runs all trunks forward over n rows (device obs) into ctx scratch `heads`; returns hld.
@@ -161,17 +170,22 @@ static int policy_forward_dev(sg_policy* p, const float* d_obs, const int64_t* d
     sg_ctx* ctx = p->ctx;
     FwdArgs a;
     a.d = p->desc; a.params = p->d_params; a.obs = d_obs; a.idx = d_idx; a.n = n; a.heads = d_heads; a.hld = hld;
-    a.wbuf_floats = max_trunk_size(p->desc, 0, p->desc.n_trunks);
+    const bool gw = sg_policy_needs_gw(ctx, p->desc);
+    a.wbuf_floats = gw ? 0 : max_trunk_size(p->desc, 0, p->desc.n_trunks);
     int MT = 4;
-    while (MT > 1 && (fwd_lds_bytes(p->desc, MT) > (size_t)ctx->lds_bytes - 1024 || 16 * (MT / 2) >= n)) MT /= 2;
-    SG_REQUIRE(fwd_lds_bytes(p->desc, MT) <= (size_t)ctx->lds_bytes,
-               "policy forward: parameter block (%zu B) does not fit LDS", fwd_lds_bytes(p->desc, MT));
+    while (MT > 1 && (fwd_lds_bytes(p->desc, MT, gw) > (size_t)ctx->lds_bytes - 1024 || 16 * (MT / 2) >= n)) MT /= 2;
+    SG_REQUIRE(fwd_lds_bytes(p->desc, MT, gw) <= (size_t)ctx->lds_bytes,
+               "policy forward: one 16-row activation tile (%zu B) does not fit LDS", fwd_lds_bytes(p->desc, MT, gw));
     const int R = 16 * MT;
     int gx = (n + R - 1) / R;
     if (gx > 4 * ctx->num_cu) gx = 4 * ctx->num_cu;
     dim3 grid(gx, p->desc.n_trunks);
-    const size_t lds = fwd_lds_bytes(p->desc, MT);
-    if (MT == 4) hipLaunchKernelGGL(k_policy_forward<4>, grid, dim3(256), lds, ctx->stream, a);
+    const size_t lds = fwd_lds_bytes(p->desc, MT, gw);
+    if (gw) {
+        if (MT == 4) hipLaunchKernelGGL((k_policy_forward<4, true>), grid, dim3(256), lds, ctx->stream, a);
+        else if (MT == 2) hipLaunchKernelGGL((k_policy_forward<2, true>), grid, dim3(256), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_policy_forward<1, true>), grid, dim3(256), lds, ctx->stream, a);
+    } else if (MT == 4) hipLaunchKernelGGL(k_policy_forward<4>, grid, dim3(256), lds, ctx->stream, a);
     else if (MT == 2) hipLaunchKernelGGL(k_policy_forward<2>, grid, dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL(k_policy_forward<1>, grid, dim3(256), lds, ctx->stream, a);
     SG_CHECK(hipGetLastError());
@@ -217,9 +231,12 @@ extern "C" int sg_policy_create(sg_ctx* ctx, int kind, int obs_dim, int act_dim,
     sg_policy* p = new sg_policy();
     p->ctx = ctx;
     p->desc = sg_make_policy_desc(kind, obs_dim, act_dim, hidden, num_feet);
-    SG_REQUIRE(fwd_lds_bytes(p->desc, 1) <= (size_t)ctx->lds_bytes,
-               "sg_policy_create: a trunk's parameter block (%d floats) does not fit the %d-byte LDS",
-               max_trunk_size(p->desc, 0, p->desc.n_trunks), ctx->lds_bytes);
+    // any width the reference's constructor accepts (a2c/arguments.py:107-109, a2c/model.py:233-253): a trunk that fits a
+    // CU's LDS runs on the LDS-resident kernels, a larger one on the global-weight instances; only one 16-row activation
+    // tile has to fit
+    SG_REQUIRE(fwd_lds_bytes(p->desc, 1, true) <= (size_t)ctx->lds_bytes - 1024,
+               "sg_policy_create: one 16-row activation tile of this policy (obs %d, hidden %d: %zu bytes) does not fit the %d-byte LDS",
+               obs_dim, hidden, fwd_lds_bytes(p->desc, 1, true), ctx->lds_bytes);
     SG_CHECK(hipMalloc((void**)&p->d_params, sizeof(float) * p->desc.total));
     SG_CHECK(hipMemsetAsync(p->d_params, 0, sizeof(float) * p->desc.total, ctx->stream));
     *out = p;
@@ -337,14 +354,13 @@ struct EnsArgs {
     int wbuf_floats, ldPmax;
 };
 
-template <int MT>
+template <int MT, bool GW = false>
 __global__ __launch_bounds__(256) void k_policy_act_ensemble(EnsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
     const SgPolicyDesc& d = a.d;
     const int tid = threadIdx.x, k = blockIdx.y, tile = blockIdx.x;
-    float* W = smem;
-    float* X = W + a.wbuf_floats;
+    float* X = smem + a.wbuf_floats;
     float* H1 = X + R * d.ldO;
     float* H2 = H1 + R * d.ldH;
     float* OUT = H2 + R * d.ldH;                       // [n_trunks][R][ldPmax]
@@ -388,9 +404,9 @@ __global__ __launch_bounds__(256) void k_policy_act_ensemble(EnsArgs a) {
     for (int t = 0; t < d.n_trunks; ++t) {
         const SgTrunk tr = d.trunk[t];
         __syncthreads();
-        sg_stage(W, a.params[k] + tr.off, tr.size / 4);
+        if (!GW) sg_stage(smem, a.params[k] + tr.off, tr.size / 4);
         __syncthreads();
-        trunk_forward<MT>(d, tr, W, X, H1, H2, OUT + t * R * a.ldPmax, tr.ldP);
+        trunk_forward<MT, GW>(d, tr, GW ? a.params[k] + tr.off : smem, X, H1, H2, OUT + t * R * a.ldPmax, tr.ldP);
     }
     __syncthreads();
     // 3. heads
@@ -420,9 +436,9 @@ __global__ __launch_bounds__(256) void k_policy_act_ensemble(EnsArgs a) {
     }
 }
 
-static size_t ens_lds_bytes(const SgPolicyDesc& d, int MT) {
+static size_t ens_lds_bytes(const SgPolicyDesc& d, int MT, bool gw = false) {
     const int R = 16 * MT;
-    return sizeof(float) * (size_t)(max_trunk_size(d, 0, d.n_trunks) + R * d.ldO + 2 * R * d.ldH + d.n_trunks * R * max_ldP(d)) +
+    return sizeof(float) * (size_t)((gw ? 0 : max_trunk_size(d, 0, d.n_trunks)) + R * d.ldO + 2 * R * d.ldH + d.n_trunks * R * max_ldP(d)) +
            sizeof(int) * (size_t)(R + 256 + 4);
 }
 
@@ -469,14 +485,19 @@ extern "C" int sg_policy_act_ensemble(sg_policy* const* policies, int n_policies
     a.d = d; a.K = n_policies; a.idx = d_idx; a.obs = d_obs; a.n = n; a.mode = deterministic ? 1 : 0;
     a.noise = (noise && !deterministic) ? d_noise : nullptr; a.seed = seed; a.stream = SG_ACT_STREAM + (uint64_t)ctx->rank;
     a.value = d_value; a.action = d_action; a.logp = d_logp;
-    a.wbuf_floats = max_trunk_size(d, 0, d.n_trunks); a.ldPmax = max_ldP(d);
+    const bool gw = sg_policy_needs_gw(ctx, d) || ens_lds_bytes(d, 1) > (size_t)ctx->lds_bytes - 1024;
+    a.wbuf_floats = gw ? 0 : max_trunk_size(d, 0, d.n_trunks); a.ldPmax = max_ldP(d);
     int MT = 2;   // 32-row tiles unless the pool is small or LDS is short
-    while (MT > 1 && (ens_lds_bytes(d, MT) > (size_t)ctx->lds_bytes - 1024 || 16 * MT * n_policies > 2 * n)) MT /= 2;
-    SG_REQUIRE(ens_lds_bytes(d, MT) <= (size_t)ctx->lds_bytes, "sg_policy_act_ensemble: policy does not fit LDS (%zu B)", ens_lds_bytes(d, MT));
+    while (MT > 1 && (ens_lds_bytes(d, MT, gw) > (size_t)ctx->lds_bytes - 1024 || 16 * MT * n_policies > 2 * n)) MT /= 2;
+    SG_REQUIRE(ens_lds_bytes(d, MT, gw) <= (size_t)ctx->lds_bytes, "sg_policy_act_ensemble: an activation tile does not fit LDS (%zu B)", ens_lds_bytes(d, MT, gw));
     const int R = 16 * MT;
     const dim3 grid((n + R - 1) / R, n_policies);
-    if (MT == 2) hipLaunchKernelGGL(k_policy_act_ensemble<2>, grid, dim3(256), ens_lds_bytes(d, 2), ctx->stream, a);
-    else hipLaunchKernelGGL(k_policy_act_ensemble<1>, grid, dim3(256), ens_lds_bytes(d, 1), ctx->stream, a);
+    const size_t lds_e = ens_lds_bytes(d, MT, gw);
+    if (gw) {
+        if (MT == 2) hipLaunchKernelGGL((k_policy_act_ensemble<2, true>), grid, dim3(256), lds_e, ctx->stream, a);
+        else hipLaunchKernelGGL((k_policy_act_ensemble<1, true>), grid, dim3(256), lds_e, ctx->stream, a);
+    } else if (MT == 2) hipLaunchKernelGGL(k_policy_act_ensemble<2>, grid, dim3(256), lds_e, ctx->stream, a);
+    else hipLaunchKernelGGL(k_policy_act_ensemble<1>, grid, dim3(256), lds_e, ctx->stream, a);
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipMemcpyAsync(value, d_value, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipMemcpyAsync(action, d_action, sizeof(float) * f_na, hipMemcpyDeviceToHost, ctx->stream));

@@ -52,17 +52,18 @@ static int stack_ldP(const SgPolicyDesc& d) {
     for (int t = 0; t < d.n_trunks; ++t) m = d.trunk[t].ldP > m ? d.trunk[t].ldP : m;
     return m;
 }
-static size_t ppo_fwd_lds(const SgPolicyDesc& d, int MT) {
+// gw: the global-weight instances (trunks larger than a CU's LDS, sg_policy_needs_gw): LDS holds the row tiles only
+static size_t ppo_fwd_lds(const SgPolicyDesc& d, int MT, bool gw) {
     const int R = 16 * MT;
-    return sizeof(float) * ((size_t)max_trunk_floats(d) + R * d.ldO + 2 * R * d.ldH);
+    return sizeof(float) * ((gw ? 0 : (size_t)max_trunk_floats(d)) + R * d.ldO + 2 * R * d.ldH);
 }
 static bool ppo_fused(const SgPolicyDesc& d, int MT) {
     const char* e = getenv("SG_PPO_FUSED");
     return d.kind == SG_POLICY_MLP && MT <= 2 && !(e && !strcmp(e, "0"));
 }
-static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT) {
+static size_t ppo_bwd_lds(const SgPolicyDesc& d, int MT, bool gw) {
     const int R = 16 * MT;
-    return sizeof(float) * ((size_t)(ppo_fused(d, MT) ? max_trunk_floats(d) : max_bwd_floats(d)) + R * d.ldO + 2 * R * d.ldH + 2 * R * stack_ldP(d) +
+    return sizeof(float) * ((gw ? 0 : (size_t)(ppo_fused(d, MT) ? max_trunk_floats(d) : max_bwd_floats(d))) + R * d.ldO + 2 * R * d.ldH + 2 * R * stack_ldP(d) +
                             ((R * d.A + 3) & ~3) + 7 * R);
 }
 
@@ -77,9 +78,14 @@ static int ppo_block_threads(int MT) {
     return (MT >= 2 && !(we && atoi(we) == 4)) ? 512 : 256;
 }
 
-static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
+static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool gw) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(ppo_block_threads(MT));
+    if (gw) {   // general-shape instances: run-time extents, weights through L2
+        if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<2, 0, 0, true>), grid, block, lds, pa);
+        else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<1, 0, 0, true>), grid, block, lds, pa);
+        return;
+    }
 #define SG_CASE(mt, o, h) \
     if (MT == mt && ko == o && kh == h) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<mt, o, h>), grid, block, lds, pa); return; }
     SG_PPO_SHAPES(SG_CASE)
@@ -96,9 +102,16 @@ static void launch_ppo_fwd_critic(sg_ctx* ctx, int MT, const SgPolicyDesc& d, di
     if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 0, 0>), grid, block, lds, pa);
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<1, 0, 0>), grid, block, lds, pa);
 }
-static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused) {
+static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused, bool gw) {
     const int ko = d.Op / 16, kh = d.Hp / 16;
     const dim3 block(ppo_block_threads(MT));
+    if (gw) {
+        if (fused && MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true, true>), grid, block, lds, pa);
+        else if (fused) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 0, 0, true, true>), grid, block, lds, pa);
+        else if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, false, true>), grid, block, lds, pa);
+        else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 0, 0, false, true>), grid, block, lds, pa);
+        return;
+    }
     if (fused) {   // Policy (independent actor / critic trunks): forward recomputed inside, no k_ppo_fwd launch
         if (MT == 1 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<1, 3, 4, true>), grid, block, lds, pa); return; }
         if (MT == 2 && ko == 3 && kh == 4) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 3, 4, true>), grid, block, lds, pa); return; }
@@ -120,9 +133,10 @@ static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
 extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg, sg_ppo** out) {
     SG_REQUIRE(ctx && p && cfg && out, "sg_ppo_create: NULL argument");
     SG_REQUIRE(cfg->ppo_epoch > 0 && cfg->num_mini_batch > 0, "sg_ppo_create: ppo_epoch and num_mini_batch must be positive");
-    SG_REQUIRE(ppo_fwd_lds(p->desc, 1) <= (size_t)ctx->lds_bytes && ppo_bwd_lds(p->desc, 1) <= (size_t)ctx->lds_bytes,
-               "sg_ppo_create: policy too large for the LDS-resident PPO kernels (%zu / %zu > %d bytes)",
-               ppo_fwd_lds(p->desc, 1), ppo_bwd_lds(p->desc, 1), ctx->lds_bytes);
+    // a policy whose trunk does not fit a CU's LDS runs on the global-weight instances; only the 16-row tiles must fit
+    SG_REQUIRE(ppo_fwd_lds(p->desc, 1, true) <= (size_t)ctx->lds_bytes && ppo_bwd_lds(p->desc, 1, true) <= (size_t)ctx->lds_bytes,
+               "sg_ppo_create: the 16-row activation tiles of this policy do not fit LDS (%zu / %zu > %d bytes)",
+               ppo_fwd_lds(p->desc, 1, true), ppo_bwd_lds(p->desc, 1, true), ctx->lds_bytes);
     SG_CHECK(hipSetDevice(ctx->device));
     sg_ppo* a = new sg_ppo();
     a->ctx = ctx; a->policy = p; a->cfg = *cfg;
@@ -323,7 +337,11 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) MT = v / 16;
     }
-    while (MT > 1 && (ppo_fwd_lds(d, MT) > (size_t)ctx->lds_bytes || ppo_bwd_lds(d, MT) > (size_t)ctx->lds_bytes)) MT /= 2;
+    // global-weight instances when a trunk (+ one 16-row tile) does not fit LDS: in the forward, or in the backward launch
+    const bool gw = sg_policy_needs_gw(ctx, d) || ppo_fwd_lds(d, 1, false) > (size_t)ctx->lds_bytes ||
+                    ppo_bwd_lds(d, 1, false) > (size_t)ctx->lds_bytes;
+    if (gw && MT > 2) MT = 2;
+    while (MT > 1 && (ppo_fwd_lds(d, MT, gw) > (size_t)ctx->lds_bytes || ppo_bwd_lds(d, MT, gw) > (size_t)ctx->lds_bytes)) MT /= 2;
     const int R = 16 * MT;
     const int G = (mb + R - 1) / R;
     const int mbp = G * R;
@@ -384,15 +402,15 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         pa.H2[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
         pa.OUT[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * ldP;
     }
-    const int wb_f = max_trunk_floats(d), wb_b = max_bwd_floats(d);
+    const int wb_f = gw ? 0 : max_trunk_floats(d), wb_b = gw ? 0 : max_bwd_floats(d);
     const bool fused = ppo_fused(d, MT);
     // SplitPolicy with more (row group, trunk) workgroups than CUs: the critic's whole fused forward + backward rides in the
     // forward launch (k_ppo_fwd_critic), the backward launch covers the two actor trunks.  SG_PPO_CRITIC_FIRST=0/1 forces it.
     const size_t lds_fc = sizeof(float) * ((size_t)wb_f + R * d.ldO + 2 * R * d.ldH + 2 * R * ldP + ((R * d.A + 3) & ~3) + 7 * R);
     const char* cfenv = getenv("SG_PPO_CRITIC_FIRST");
-    const bool crit_first = !fused && d.kind == SG_POLICY_SPLIT && MT <= 2 && lds_fc <= (size_t)ctx->lds_bytes &&
+    const bool crit_first = !gw && !fused && d.kind == SG_POLICY_SPLIT && MT <= 2 && lds_fc <= (size_t)ctx->lds_bytes &&
                             (cfenv ? cfenv[0] == '1' : G * d.n_trunks > ctx->num_cu);
-    const size_t lds_f = ppo_fwd_lds(d, MT), lds_b = ppo_bwd_lds(d, MT);
+    const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
@@ -415,14 +433,14 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                     pa.wbuf_floats = wb_f;
                     launch_ppo_fwd_critic(ctx, MT, d, dim3(G, d.n_trunks), lds_fc > lds_f ? lds_fc : lds_f, pa);
                     pa.wbuf_floats = wb_b;
-                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks - 1), lds_b, pa, false);   // trunks 0, 1: the actors
+                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks - 1), lds_b, pa, false, false);   // trunks 0, 1: the actors
                 } else {
                     if (!fused) {
                         pa.wbuf_floats = wb_f;
-                        launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa);
+                        launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa, gw);
                     }
                     pa.wbuf_floats = fused ? wb_f : wb_b;
-                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused);
+                    launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused, gw);
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
                           d.total, a->d_grad, a->d_part);
@@ -455,7 +473,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {

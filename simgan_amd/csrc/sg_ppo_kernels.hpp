@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void k_ppo_epoch_gather(EpochGatherArgs a) {
 }
 
 // --------------------------------------------------------------------------------- forward
-template <int MT, int KO, int KH>
+// GW (sg_gemm.hpp): the trunk's parameter block is read from global memory by the layer GEMMs instead of being staged
+// into LDS -- the general-shape instances for trunks larger than a CU's LDS (run-time extents only: KO = KH = 0).
+template <int MT, int KO, int KH, bool GW = false>
 __device__ __forceinline__ void sg_ppo_fwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = 16 * MT;
@@ -111,22 +113,22 @@ __device__ __forceinline__ void sg_ppo_fwd_body(const PpoArgs& a, const int t, c
     const int tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
     const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP;
-    float* W = smem;
-    float* X = W + a.wbuf_floats;
+    const float* W = GW ? a.params + tr.off : smem;
+    float* X = smem + a.wbuf_floats;
     float* H1 = X + R * ldO;
     float* H2 = H1 + R * ldH;
     const int row0 = bx * R;
 
     SG_PPO_STAMP(0);
     float4 wv[12];
-    sg_stage_issue<12>(wv, a.params + tr.off, tr.size / 4);
+    if (!GW) sg_stage_issue<12>(wv, a.params + tr.off, tr.size / 4);
     {   // the row tile: contiguous in the epoch's permuted copy
         const float4* gx = reinterpret_cast<const float4*>(a.X + (size_t)row0 * ldO);
         float4* lx = reinterpret_cast<float4*>(X);
         for (int i = tid; i < R * ldO / 4; i += blockDim.x) lx[i] = gx[i];
     }
     SG_PPO_STAMP(1);
-    sg_stage_commit<12>(W, wv, a.params + tr.off, tr.size / 4);
+    if (!GW) sg_stage_commit<12>(smem, wv, a.params + tr.off, tr.size / 4);
     __syncthreads();
     SG_PPO_STAMP(2);
     const float* b1 = W + tr.b1;
@@ -135,28 +137,28 @@ __device__ __forceinline__ void sg_ppo_fwd_body(const PpoArgs& a, const int t, c
     float* gH1 = a.H1[t] + (size_t)row0 * ldH;
     float* gH2 = a.H2[t] + (size_t)row0 * ldH;
     float* gOUT = a.OUT[t] + (size_t)row0 * ldP;
-    sg_layer_nt_u<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) {
+    sg_layer_nt_u<MT, GW>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b1[c]);
         H1[r * ldH + c] = h;
         gH1[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(3);
-    sg_layer_nt_u<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) {
+    sg_layer_nt_u<MT, GW>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) {
         const float h = sg_tanh(v + b2[c]);
         H2[r * ldH + c] = h;
         gH2[r * ldH + c] = h;
     });
     __syncthreads();
     SG_PPO_STAMP(4);
-    sg_layer_nt_u<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
+    sg_layer_nt_u<MT, GW>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { gOUT[r * ldP + c] = v + bh[c]; });
     __syncthreads();
     SG_PPO_STAMP(5);
 }
 
-template <int MT, int KO, int KH>
+template <int MT, int KO, int KH, bool GW = false>
 __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
-    sg_ppo_fwd_body<MT, KO, KH>(a, blockIdx.y, blockIdx.x);
+    sg_ppo_fwd_body<MT, KO, KH, GW>(a, blockIdx.y, blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------- backward
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
 // (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per SIMD hide each
 // other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights staged once and
 // one slab per 32 rows.
-template <int MT, int KO, int KH, bool FUSED>
+template <int MT, int KO, int KH, bool FUSED, bool GW = false>
 __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (No spare workgroup for Adam's bias corrections any more: with G x trunks = 256 row-group blocks, two extra blocks
@@ -186,9 +188,9 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     // LDS image of the trunk block from w2 on (w1/b1 are not needed going backward), or all of it when fused
     float* Wimg = smem;
     const int w_first = FUSED ? 0 : tr.w2;
-    const float* W = Wimg - w_first;               // so that W + tr.<off> addresses the block as usual
+    const float* W = GW ? a.params + tr.off : Wimg - w_first;   // so that W + tr.<off> addresses the block as usual
     const int wfl = tr.size - w_first;
-    float* X = Wimg + a.wbuf_floats;
+    float* X = Wimg + a.wbuf_floats;                            // GW: wbuf_floats = 0, LDS holds the row tiles only
     float* H1 = X + R * ldO;
     float* H2 = H1 + R * ldH;
     float* O0 = H2 + R * ldH;                      // critic: value head; actors: trunk 0's head outputs
@@ -204,7 +206,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     SG_PPO_WALL(6);
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
-    sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
+    if (!GW) sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
     constexpr int UX = MT <= 2 ? 4 : 8;          // float4 per thread for an [R][ld <= 116] tile at 256 threads
     constexpr int UO = MT <= 2 ? 2 : 4;          // ... for an [R][ldP <= 64] tile
     const int ta = critic ? t : 0;
@@ -250,20 +252,20 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
     SG_PPO_STAMP(0);
-    sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
+    if (!GW) sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
     __syncthreads();
     SG_PPO_STAMP(1);
     if (FUSED) {   // forward on this row group (a2c/model.py:255-264, a2c/distributions.py:109-118), activations stay in LDS
         const float* b1 = W + tr.b1;
         const float* b2 = W + tr.b2;
         const float* bh = W + tr.bh;
-        sg_layer_nt_u<MT>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
+        sg_layer_nt_u<MT, GW>(X, ldO, W + tr.w1, ldO, Op, Hp, [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
         __syncthreads();
         SG_PPO_STAMP(2);
-        sg_layer_nt_u<MT>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
+        sg_layer_nt_u<MT, GW>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
         SG_PPO_STAMP(3);
-        sg_layer_nt_u<MT>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
+        sg_layer_nt_u<MT, GW>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
         __syncthreads();
         SG_PPO_STAMP(4);
     }
@@ -460,9 +462,9 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     SG_PPO_WALL(7);
 }
 
-template <int MT, int KO, int KH, bool FUSED = false>
+template <int MT, int KO, int KH, bool FUSED = false, bool GW = false>
 __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
-    sg_ppo_bwd_body<MT, KO, KH, FUSED>(a, blockIdx.y, blockIdx.x);
+    sg_ppo_bwd_body<MT, KO, KH, FUSED, GW>(a, blockIdx.y, blockIdx.x);
 }
 
 // SplitPolicy at minibatches whose (row groups x 3 trunks) exceed the CU count: the critic trunk needs no actor output (its

@@ -266,3 +266,43 @@ def test_refine_iteration():
         assert_close(losses, g[f"it{j}_ppo_losses"], what="ppo losses")
         assert_close(pi, g[f"it{j}_pi_params"], what="pi params")
         obs[0], masks[0], bad[0] = obs[T], masks[T], bad[T]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/sg_cpu_fast.c -- the batched, vectorised CPU implementation bench.py times as `cpu_baseline` -- against the
+# oracle: same gradients and loss sums at the suite's tolerance, for both policy kinds and the discriminator.
+@pytest.mark.parametrize("kind,O,A,H,f", [("mlp", 47, 12, 64, 1), ("mlp", 11, 3, 64, 1), ("split", 14, 7, 100, 1), ("split", 64, 28, 100, 4),
+                                          ("mlp", 5, 2, 7, 1)])
+def test_fast_cpu_ppo_gradient_equals_the_oracle(kind, O, A, H, f):
+    rng = np.random.default_rng(O * 100 + H)
+    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f)
+    n = 203                                      # not a multiple of the 4-row panels
+    # (a state-dependent log-std head on N(0, 0.15) weights gives log-probs of -1000 and sums that cancel to 1e-4 of their terms)
+    par = (rng.standard_normal(orc.policy_num_params(d)) * (0.15 if kind == "mlp" else 0.05)).astype(np.float32)
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    act = rng.standard_normal((n, A)).astype(np.float32)
+    v_now, lp, _ = orc.policy_evaluate(d, par, obs, act)
+    old_logp = (lp[:, 0] + 0.3 * rng.standard_normal(n)).astype(np.float32)      # ratios on both sides of the clip
+    vpred = (v_now[:, 0] + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    ret = (v_now[:, 0] + rng.standard_normal(n)).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    rows = rng.permutation(n)[:150]
+    for ecoef, clipped in ((0.0, True), (0.01, False)):
+        cfg = orc.ppo_cfg(0.2, 1, 1, 0.5, ecoef, 3e-4, 1e-5, 0.5, clipped)
+        G0, s0 = orc.ppo_grad_rows(d, par, cfg, obs, act, vpred, ret, old_logp, adv, rows, 1.0 / rows.size)
+        G1, s1 = orc.ppo_grad_rows_fast(d, par, cfg, obs, act, vpred, ret, old_logp, adv, rows, 1.0 / rows.size)
+        assert_close(s1, s0, what="loss sums")
+        assert np.abs(G1 - G0).max() <= 1e-4 * np.abs(G0).max() + 1e-7, (np.abs(G1 - G0).max(), np.abs(G0).max())
+
+
+@pytest.mark.parametrize("F,Hd,nb", [(86, 100, 128), (25, 100, 128), (7, 5, 3), (86, 100, 37)])
+def test_fast_cpu_discriminator_gradient_equals_the_oracle(F, Hd, nb):
+    rng = np.random.default_rng(F + Hd + nb)
+    par = (rng.standard_normal(orc.disc_num_params(F, Hd)) * 0.2).astype(np.float32)
+    e = rng.standard_normal((nb, F)).astype(np.float32)
+    p = (rng.standard_normal((nb, F)) * 0.8 + 0.3).astype(np.float32)
+    al = rng.random(nb).astype(np.float32)
+    G0, s0 = orc.disc_grad_rows(F, Hd, par, e, p, al, 1.0 / nb)
+    G1, s1 = orc.disc_grad_rows_fast(F, Hd, par, e, p, al, 1.0 / nb)
+    assert_close(s1, s0, what="loss sums")
+    assert np.abs(G1 - G0).max() <= 1e-4 * np.abs(G0).max() + 1e-7, (np.abs(G1 - G0).max(), np.abs(G0).max())

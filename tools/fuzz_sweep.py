@@ -18,12 +18,16 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 out = sys.argv[3] if len(sys.argv) > 3 else None
 mp = pytest.MonkeyPatch()
-res = {"ppo": {"cases": 0, "failures": []}, "disc_thin": {"cases": 0, "failures": []}, "disc_wide": {"cases": 0, "failures": []}}
+res = {k: {"cases": 0, "failures": []} for k in ("ppo", "disc_thin", "disc_wide", "ppo_widths_to_256", "disc_widths_to_256")}
 t0 = time.time()
 for seed in range(first, first + n):
-    for name, fn in (("ppo", lambda: fz.test_ppo_random_shapes_vs_oracle.__wrapped__(sg, seed) if hasattr(fz.test_ppo_random_shapes_vs_oracle, "__wrapped__") else fz.test_ppo_random_shapes_vs_oracle(sg, seed)),
+    for name, fn in (("ppo", lambda: fz._ppo_case(sg, seed)),
                      ("disc_thin", lambda: fz.test_disc_random_shapes_vs_oracle(sg, seed, "thin", mp)),
-                     ("disc_wide", lambda: fz.test_disc_random_shapes_vs_oracle(sg, seed, "wide", mp))):
+                     ("disc_wide", lambda: fz.test_disc_random_shapes_vs_oracle(sg, seed, "wide", mp)),
+                     # round 4: the whole range the reference's constructors accept (hidden / input widths up to 256);
+                     # a refusal at creation counts as a failure
+                     ("ppo_widths_to_256", lambda: fz._ppo_case(sg, seed, wide=True)),
+                     ("disc_widths_to_256", lambda: fz._disc_case(sg, seed, "thin", mp, wide=True))):
         res[name]["cases"] += 1
         try:
             fn()
