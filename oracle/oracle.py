@@ -202,8 +202,9 @@ def ppo_grad_rows(d, params, cfg, obs, actions, value_preds, returns, old_logp, 
     return G, np.array(list(sums))
 
 
-def ppo_grad_rows_fast(d, params, cfg, obs, actions, value_preds, returns, old_logp, adv, rows, inv_B, native=False):
-    """oracle/sg_cpu_fast.c:fast_ppo_grad_rows -- same contract as ppo_grad_rows, batched GEMMs."""
+def ppo_grad_rows_fast(d, params, cfg, obs, actions, value_preds, returns, old_logp, adv, rows, inv_B, native=False, n_threads=1):
+    """oracle/sg_cpu_fast.c:fast_ppo_grad_rows -- same contract as ppo_grad_rows, batched GEMMs (n_threads > 1: rows split
+    over an OpenMP team)."""
     params, pp = _f(params)
     obs, po = _f(obs)
     actions, pa = _f(actions)
@@ -214,12 +215,16 @@ def ppo_grad_rows_fast(d, params, cfg, obs, actions, value_preds, returns, old_l
     rows, prow = _i64(rows)
     G = np.zeros(params.size, np.float32)
     sums = (C.c_double * 3)(0, 0, 0)
-    fast_lib(native)[0].fast_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
-                                           int(rows.size), C.c_float(inv_B), _fp(G), sums)
+    if n_threads > 1:
+        fast_lib(native)[0].fast_ppo_grad_rows_mt(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow, int(rows.size),
+                                                  C.c_float(inv_B), _fp(G), sums, int(n_threads), C.c_int64(params.size))
+    else:
+        fast_lib(native)[0].fast_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
+                                               int(rows.size), C.c_float(inv_B), _fp(G), sums)
     return G, np.array(list(sums))
 
 
-def disc_grad_rows_fast(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda_=10.0, native=False):
+def disc_grad_rows_fast(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda_=10.0, native=False, n_threads=1):
     """oracle/sg_cpu_fast.c:fast_disc_grad_rows -- same contract as disc_grad_rows, batched GEMMs."""
     params, pp = _f(params)
     expert_rows, pe = _f(expert_rows)
@@ -228,7 +233,10 @@ def disc_grad_rows_fast(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, l
     nb = expert_rows.shape[0]
     G = np.zeros(params.size, np.float32)
     sums = (C.c_double * 3)(0, 0, 0)
-    fast_lib(native)[0].fast_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums)
+    if n_threads > 1:
+        fast_lib(native)[0].fast_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums, int(n_threads))
+    else:
+        fast_lib(native)[0].fast_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums)
     return G, np.array(list(sums))
 
 

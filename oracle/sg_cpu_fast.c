@@ -346,3 +346,49 @@ void fast_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_
     }
     free(buf);
 }
+
+/* ------------------------------------------------------------------------------------------------ all cores */
+/* Rows split into n_threads contiguous chunks, each chunk through the batched routine into a private gradient, chunks
+ * summed in chunk order (the all-cores leg of bench.py's cpu_baseline). */
+void fast_ppo_grad_rows_mt(const orc_policy_dims *d, const float *P, const orc_ppo_cfg *cfg, const float *obs,
+                           const float *actions, const float *value_preds, const float *returns, const float *old_logp,
+                           const float *adv, const int64_t *rows, int n_rows, float inv_B, float *G, double *sums,
+                           int n_threads, int64_t n_params) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_rows) n_threads = n_rows;
+    float *Gt = (float *)calloc((size_t)n_threads * n_params, sizeof(float));
+    double *St = (double *)calloc((size_t)n_threads * 3, sizeof(double));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; ++t) {
+        const int lo = (int)((int64_t)n_rows * t / n_threads), hi = (int)((int64_t)n_rows * (t + 1) / n_threads);
+        fast_ppo_grad_rows(d, P, cfg, obs, actions, value_preds, returns, old_logp, adv, rows + lo, hi - lo, inv_B,
+                           Gt + (size_t)t * n_params, St + 3 * t);
+    }
+    for (int t = 0; t < n_threads; ++t) {
+        for (int64_t i = 0; i < n_params; ++i) G[i] += Gt[(size_t)t * n_params + i];
+        for (int i = 0; i < 3; ++i) sums[i] += St[3 * t + i];
+    }
+    free(Gt);
+    free(St);
+}
+
+void fast_disc_grad_rows_mt(int F, int Hd, const float *P, const float *expert_rows, const float *policy_rows,
+                            const float *alpha, int nb, float inv_B, float lambda_, float *G, double *sums, int n_threads) {
+    const int64_t n = (int64_t)Hd * F + Hd + (int64_t)Hd * Hd + Hd + Hd + 1;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > nb) n_threads = nb;
+    float *Gt = (float *)calloc((size_t)n_threads * n, sizeof(float));
+    double *St = (double *)calloc((size_t)n_threads * 3, sizeof(double));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; ++t) {
+        const int lo = (int)((int64_t)nb * t / n_threads), hi = (int)((int64_t)nb * (t + 1) / n_threads);
+        fast_disc_grad_rows(F, Hd, P, expert_rows + (size_t)lo * F, policy_rows + (size_t)lo * F, alpha + lo, hi - lo, inv_B,
+                            lambda_, Gt + (size_t)t * n, St + 3 * t);
+    }
+    for (int t = 0; t < n_threads; ++t) {
+        for (int64_t i = 0; i < n; ++i) G[i] += Gt[(size_t)t * n + i];
+        for (int i = 0; i < 3; ++i) sums[i] += St[3 * t + i];
+    }
+    free(Gt);
+    free(St);
+}

@@ -11,7 +11,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
-for w in northstar hopper laikago refine; do
+for w in northstar hopper laikago refine hopper_ppo; do
     bash tools/profile_workload.sh $tag $w > $out/${tag}_${w}_profile.log 2>&1
 done
 bash tools/profile_calibration.sh $tag 1024 > $out/${tag}_calibration.log 2>&1
@@ -21,4 +21,4 @@ done
 SG_PARITY_RECORD=$out/${tag}_parity.json timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_pytest_gpu.txt
 rm -f $out/${tag}_*_profile.log $out/${tag}_calibration.log $out/${tag}_*.err
 tail -3 $out/${tag}_pytest_gpu.txt
-for w in northstar hopper laikago refine; do head -9 $out/${tag}_${w}_kernel_trace.txt | tail -6; cut -c1-160 $out/${tag}_${w}_bench.json; done
+for w in northstar hopper laikago refine hopper_ppo; do head -9 $out/${tag}_${w}_kernel_trace.txt | tail -6; cut -c1-160 $out/${tag}_${w}_bench.json; done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel trace + FETCH_SIZE / WRITE_SIZE PMC passes (separate runs) + the bench line for ONE workload of bench.py.
-# Usage (repo root, GPU box):  bash tools/profile_workload.sh <tag> <northstar|hopper|laikago|refine>
+# Usage (repo root, GPU box):  bash tools/profile_workload.sh <tag> <northstar|hopper|laikago|refine|hopper_ppo>
 # Writes gpurun_out/<tag>_<workload>_{kernel_trace,pmc_fetch_size,pmc_write_size}.txt and <tag>_<workload>_bench.json;
 # copy what should be judged into profiles/ and regenerate profiles/traffic.json with tools/make_traffic.py.
 set -u
@@ -9,6 +9,10 @@ wl=${2:-northstar}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
+python - <<PYEOF
+import hashlib, json
+json.dump({"lib_sha256": hashlib.sha256(open("$root/simgan_amd/libsimgan_hip.so", "rb").read()).hexdigest()}, open("$out/${tag}_${wl}_build.json", "w"))
+PYEOF
 cd /tmp && export TMPDIR=/tmp
 run_prof() {  # name, rocprofv3 args...
     local name=$1; shift
