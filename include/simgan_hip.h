@@ -77,6 +77,11 @@ enum { SG_POLICY_MLP = 0, SG_POLICY_SPLIT = 1 };
  * requires act_dim == 7*num_feet, a2c/model_split.py:205). Parameters start at zero. */
 SG_API int sg_policy_create(sg_ctx *ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet,
                      sg_policy **out);
+/* The same with a critic trunk of its own width (critic_hidden; 0 = hidden): Policy.reset_critic(obs_shape) rebuilds a
+ * 64-unit critic beside an actor of ANY hidden size (a2c/model.py:80-87; a2c/main.py:85 calls it on every warm start).
+ * state_dict order and entry points are unchanged; base.critic.* and base.critic_linear take the critic's width. */
+SG_API int sg_policy_create2(sg_ctx *ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet, int critic_hidden,
+                             sg_policy **out);
 SG_API int sg_policy_destroy(sg_policy *p);
 SG_API int sg_policy_num_params(const sg_policy *p, int64_t *n);
 /* nn.Module.load_state_dict / state_dict, flattened. */

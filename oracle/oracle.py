@@ -17,7 +17,7 @@ KIND_MLP, KIND_SPLIT = 0, 1
 
 class PolicyDims(C.Structure):
     _fields_ = [("kind", C.c_int), ("O", C.c_int), ("A", C.c_int), ("H", C.c_int),
-                ("num_feet", C.c_int)]
+                ("num_feet", C.c_int), ("Hc", C.c_int)]
 
 
 class PPOCfg(C.Structure):
@@ -98,8 +98,9 @@ def _i64(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
-def dims(kind, O, A, H, num_feet=1):
-    return PolicyDims(kind, O, A, H, num_feet)
+def dims(kind, O, A, H, num_feet=1, Hc=0):
+    """Hc: hidden size of the critic trunk when it differs from H (Policy.reset_critic, a2c/model.py:80-87); 0 = H."""
+    return PolicyDims(kind, O, A, H, num_feet, 0 if Hc == H else Hc)
 
 
 def policy_num_params(d):

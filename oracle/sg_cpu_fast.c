@@ -21,7 +21,7 @@
 #include <string.h>
 
 #define ORC_KIND_MLP 0
-typedef struct { int kind, O, A, H, num_feet; } orc_policy_dims;
+typedef struct { int kind, O, A, H, num_feet, Hc; } orc_policy_dims;   /* Hc: critic trunk width when it differs from H (0 = H) */
 typedef struct {
     float clip_param; int ppo_epoch; int num_mini_batch; float value_loss_coef; float entropy_coef; float lr; float eps;
     float max_grad_norm; int use_clipped_value_loss;
@@ -216,37 +216,44 @@ void fast_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_
                         const float *adv, const int64_t *rows, int n_rows, float inv_B, float *G, double *sums) {
     const int O = d->O, H = d->H, A = d->A, mlp = d->kind == ORC_KIND_MLP, nt = mlp ? 2 : 3, ct = nt - 1, R = n_rows;
     const int nc = 4 * d->num_feet, na = 3 * d->num_feet;
+    const int Hc = d->Hc > 0 ? d->Hc : H, HM = Hc > H ? Hc : H;       /* critic width, widest trunk */
+    int Ht[3];
     size_t w1[3], b1[3], w2[3], b2[3], o = 0;
-    for (int t = 0; t < nt; ++t) { w1[t] = o; o += (size_t)H * O; b1[t] = o; o += H; w2[t] = o; o += (size_t)H * H; b2[t] = o; o += H; }
-    const size_t vw = o, vb = vw + H;
+    for (int t = 0; t < nt; ++t) {
+        const int h = t == ct ? Hc : H;
+        Ht[t] = h;
+        w1[t] = o; o += (size_t)h * O; b1[t] = o; o += h; w2[t] = o; o += (size_t)h * h; b2[t] = o; o += h;
+    }
+    const size_t vw = o, vb = vw + Hc;
     o = vb + 1;
     size_t mw = 0, mb = 0, lsd = 0, cmw = 0, cmb = 0, amw = 0, amb = 0, clw = 0, clb = 0, alw = 0, alb = 0;
     if (mlp) { mw = o; mb = mw + (size_t)A * H; lsd = mb + A; }
     else { cmw = o; cmb = cmw + (size_t)nc * H; amw = cmb + nc; amb = amw + (size_t)na * H; clw = amb + na; clb = clw + (size_t)nc * H;
            alw = clb + nc; alb = alw + (size_t)na * H; }
-    const size_t wmax = (size_t)H * (O > H ? O : H);
-    float *buf = (float *)malloc(sizeof(float) * (wmax + (size_t)R * O + (size_t)nt * R * H * 2 + (size_t)R * H * 2 + (size_t)R * A * 4 + 4 * (size_t)R + 64));
-    float *Wt = buf, *X = Wt + wmax, *H1 = X + (size_t)R * O, *H2 = H1 + (size_t)nt * R * H;
-    float *DH = H2 + (size_t)nt * R * H, *DZ = DH + (size_t)R * H;            /* [R,H] each */
-    float *MEAN = DZ + (size_t)R * H, *LS = MEAN + (size_t)R * A, *DM = LS + (size_t)R * A, *DL = DM + (size_t)R * A;
+    const size_t wmax = (size_t)HM * (O > HM ? O : HM);
+    float *buf = (float *)malloc(sizeof(float) * (wmax + (size_t)R * O + (size_t)nt * R * HM * 2 + (size_t)R * HM * 2 + (size_t)R * A * 4 + 4 * (size_t)R + 64));
+    float *Wt = buf, *X = Wt + wmax, *H1 = X + (size_t)R * O, *H2 = H1 + (size_t)nt * R * HM;   /* trunk t: [R, Ht[t]] at t*R*HM */
+    float *DH = H2 + (size_t)nt * R * HM, *DZ = DH + (size_t)R * HM;          /* [R, Ht] each */
+    float *MEAN = DZ + (size_t)R * HM, *LS = MEAN + (size_t)R * A, *DM = LS + (size_t)R * A, *DL = DM + (size_t)R * A;
     float *V = DL + (size_t)R * A, *DV = V + R;
     for (int r = 0; r < R; ++r) memcpy(X + (size_t)r * O, obs + (size_t)rows[r] * O, sizeof(float) * O);
     /* forward, trunk by trunk (a2c/model.py:255-264, a2c/model_split.py:187-198) */
     for (int t = 0; t < nt; ++t) {
-        float *h1 = H1 + (size_t)t * R * H, *h2 = H2 + (size_t)t * R * H;
-        transpose(H, O, P + w1[t], Wt);
-        gemm_nn(R, H, O, X, O, Wt, H, h1, H, 0);
-        bias_tanh(R, H, h1, P + b1[t]);
-        transpose(H, H, P + w2[t], Wt);
-        gemm_nn(R, H, H, h1, H, Wt, H, h2, H, 0);
-        bias_tanh(R, H, h2, P + b2[t]);
+        const int h = Ht[t];
+        float *h1 = H1 + (size_t)t * R * HM, *h2 = H2 + (size_t)t * R * HM;
+        transpose(h, O, P + w1[t], Wt);
+        gemm_nn(R, h, O, X, O, Wt, h, h1, h, 0);
+        bias_tanh(R, h, h1, P + b1[t]);
+        transpose(h, h, P + w2[t], Wt);
+        gemm_nn(R, h, h, h1, h, Wt, h, h2, h, 0);
+        bias_tanh(R, h, h2, P + b2[t]);
     }
     /* heads (small: A <= 28 outputs): dot products per row */
-    const float *h2c = H2 + (size_t)ct * R * H, *h2a = H2, *h2b = H2 + (size_t)R * H;
+    const float *h2c = H2 + (size_t)ct * R * HM, *h2a = H2, *h2b = H2 + (size_t)R * HM;
     for (int r = 0; r < R; ++r) {
-        const float *hc = h2c + (size_t)r * H;
+        const float *hc = h2c + (size_t)r * Hc;
         float v = P[vb];
-        for (int j = 0; j < H; ++j) v += hc[j] * P[vw + j];
+        for (int j = 0; j < Hc; ++j) v += hc[j] * P[vw + j];
         V[r] = v;
         float *mean = MEAN + (size_t)r * A, *ls = LS + (size_t)r * A;
         for (int k = 0; k < A; ++k) {
@@ -304,15 +311,15 @@ void fast_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_
     sums[0] += s_v; sums[1] += s_a; sums[2] += s_e;
     /* backward, trunk by trunk */
     for (int t = 0; t < nt; ++t) {
-        const float *h1 = H1 + (size_t)t * R * H, *h2 = H2 + (size_t)t * R * H;
-        memset(DH, 0, sizeof(float) * (size_t)R * H);
+        const float *h1 = H1 + (size_t)t * R * HM, *h2 = H2 + (size_t)t * R * HM;
+        memset(DH, 0, sizeof(float) * (size_t)R * HM);
         if (t == ct) {
             for (int r = 0; r < R; ++r) {
                 const float g = DV[r];
-                const float *h = h2 + (size_t)r * H;
-                float *dh = DH + (size_t)r * H;
+                const float *h = h2 + (size_t)r * Hc;
+                float *dh = DH + (size_t)r * Hc;
                 G[vb] += g;
-                for (int j = 0; j < H; ++j) { G[vw + j] += g * h[j]; dh[j] += g * P[vw + j]; }
+                for (int j = 0; j < Hc; ++j) { G[vw + j] += g * h[j]; dh[j] += g * P[vw + j]; }
             }
         } else {
             /* head groups this trunk feeds: (grad rows source, first action dim, count, weight offset, bias offset) */
@@ -336,13 +343,14 @@ void fast_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_
                 }
             if (mlp) for (int r = 0; r < R; ++r) for (int k = 0; k < A; ++k) G[lsd + k] += DL[(size_t)r * A + k];
         }
-        for (size_t i = 0; i < (size_t)R * H; ++i) DZ[i] = DH[i] * (1.0f - h2[i] * h2[i]);
-        gemm_tn_acc(H, H, R, DZ, H, h1, H, G + w2[t], H);
-        colsum_acc(R, H, DZ, G + b2[t]);
-        gemm_nn(R, H, H, DZ, H, P + w2[t], H, DH, H, 0);                      /* dh1 = dz2 W2 */
-        for (size_t i = 0; i < (size_t)R * H; ++i) DZ[i] = DH[i] * (1.0f - h1[i] * h1[i]);
-        gemm_tn_acc(H, O, R, DZ, H, X, O, G + w1[t], O);
-        colsum_acc(R, H, DZ, G + b1[t]);
+        const int h = Ht[t];
+        for (size_t i = 0; i < (size_t)R * h; ++i) DZ[i] = DH[i] * (1.0f - h2[i] * h2[i]);
+        gemm_tn_acc(h, h, R, DZ, h, h1, h, G + w2[t], h);
+        colsum_acc(R, h, DZ, G + b2[t]);
+        gemm_nn(R, h, h, DZ, h, P + w2[t], h, DH, h, 0);                      /* dh1 = dz2 W2 */
+        for (size_t i = 0; i < (size_t)R * h; ++i) DZ[i] = DH[i] * (1.0f - h1[i] * h1[i]);
+        gemm_tn_acc(h, O, R, DZ, h, X, O, G + w1[t], O);
+        colsum_acc(R, h, DZ, G + b1[t]);
     }
     free(buf);
 }

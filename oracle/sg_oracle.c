@@ -42,6 +42,8 @@ typedef struct {
     int kind;     /* ORC_KIND_* */
     int O, A, H;  /* obs dim, action dim, hidden size */
     int num_feet; /* SplitPolicy only; A == 7*num_feet (a2c/model_split.py:205) */
+    int Hc;       /* hidden size of the CRITIC trunk when it differs from H (0 = H): Policy.reset_critic rebuilds a 64-unit
+                   * critic beside an actor of any width (a2c/model.py:80-87, called by a2c/main.py:85 on every warm start) */
 } orc_policy_dims;
 
 typedef struct {
@@ -98,6 +100,7 @@ static float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 typedef struct {
     int n_trunks;        /* 2 (MLP: actor, critic) or 3 (split: contact, actuator, critic) */
+    int Ht[3], Hmax;     /* hidden size per trunk (the critic's may differ: orc_policy_dims.Hc) */
     size_t w1[3], b1[3], w2[3], b2[3];
     size_t vw, vb;       /* value head */
     /* MLP */
@@ -114,13 +117,17 @@ static pol_layout policy_layout(const orc_policy_dims *d) {
     size_t o = 0;
     int O = d->O, H = d->H, A = d->A;
     L.n_trunks = d->kind == ORC_KIND_MLP ? 2 : 3;
+    L.Hmax = H;
     for (int t = 0; t < L.n_trunks; ++t) {
-        L.w1[t] = o; o += (size_t)H * O;
-        L.b1[t] = o; o += H;
-        L.w2[t] = o; o += (size_t)H * H;
-        L.b2[t] = o; o += H;
+        const int Ht = (t == L.n_trunks - 1 && d->Hc > 0) ? d->Hc : H;
+        L.Ht[t] = Ht;
+        if (Ht > L.Hmax) L.Hmax = Ht;
+        L.w1[t] = o; o += (size_t)Ht * O;
+        L.b1[t] = o; o += Ht;
+        L.w2[t] = o; o += (size_t)Ht * Ht;
+        L.b2[t] = o; o += Ht;
     }
-    L.vw = o; o += H;
+    L.vw = o; o += L.Ht[L.n_trunks - 1];
     L.vb = o; o += 1;
     if (d->kind == ORC_KIND_MLP) {
         L.mw = o; o += (size_t)A * H;
@@ -153,25 +160,29 @@ static int critic_trunk(const orc_policy_dims *d) { return d->kind == ORC_KIND_M
 static void policy_row_forward(const orc_policy_dims *d, const pol_layout *L, const float *P,
                                const float *x, float *h1, float *h2, float *value, float *mean,
                                float *logstd) {
-    int O = d->O, H = d->H, A = d->A;
+    /* h1 / h2 are [n_trunks][Hmax]; trunk t uses its first Ht[t] entries */
+    int O = d->O, H = L->Hmax, A = d->A;
     float *z = (float *)malloc(sizeof(float) * H);
     for (int t = 0; t < L->n_trunks; ++t) {
-        linear(P + L->w1[t], P + L->b1[t], x, H, O, z);
-        for (int i = 0; i < H; ++i) h1[t * H + i] = tanhf(z[i]);
-        linear(P + L->w2[t], P + L->b2[t], h1 + t * H, H, H, z);
-        for (int i = 0; i < H; ++i) h2[t * H + i] = tanhf(z[i]);
+        const int Ht = L->Ht[t];
+        linear(P + L->w1[t], P + L->b1[t], x, Ht, O, z);
+        for (int i = 0; i < Ht; ++i) h1[t * H + i] = tanhf(z[i]);
+        linear(P + L->w2[t], P + L->b2[t], h1 + t * H, Ht, Ht, z);
+        for (int i = 0; i < Ht; ++i) h2[t * H + i] = tanhf(z[i]);
     }
     free(z);
     int ct = critic_trunk(d);
-    linear(P + L->vw, P + L->vb, h2 + ct * H, 1, H, value);
+    linear(P + L->vw, P + L->vb, h2 + ct * H, 1, L->Ht[ct], value);
+    H = d->H;   /* the actor heads below read actor trunks, which are all H wide */
     if (d->kind == ORC_KIND_MLP) {
         linear(P + L->mw, P + L->mb, h2, A, H, mean);
         for (int k = 0; k < A; ++k) logstd[k] = P[L->logstd + k];
     } else {
+        const int S = L->Hmax;   /* stride between the trunks' activation rows */
         linear(P + L->cmw, P + L->cmb, h2, L->nc, H, mean);
-        linear(P + L->amw, P + L->amb, h2 + H, L->na, H, mean + L->nc);
+        linear(P + L->amw, P + L->amb, h2 + S, L->na, H, mean + L->nc);
         linear(P + L->clw, P + L->clb, h2, L->nc, H, logstd);
-        linear(P + L->alw, P + L->alb, h2 + H, L->na, H, logstd + L->nc);
+        linear(P + L->alw, P + L->alb, h2 + S, L->na, H, logstd + L->nc);
     }
 }
 
@@ -199,8 +210,8 @@ static float normal_entropy_sum(const float *logstd, int A) {
 void orc_policy_forward(const orc_policy_dims *d, const float *P, const float *obs, int n,
                         float *value, float *mean, float *logstd) {
     pol_layout L = policy_layout(d);
-    float *h1 = (float *)malloc(sizeof(float) * 3 * d->H);
-    float *h2 = (float *)malloc(sizeof(float) * 3 * d->H);
+    float *h1 = (float *)malloc(sizeof(float) * 3 * L.Hmax);
+    float *h2 = (float *)malloc(sizeof(float) * 3 * L.Hmax);
     for (int r = 0; r < n; ++r)
         policy_row_forward(d, &L, P, obs + (size_t)r * d->O, h1, h2, value + r,
                            mean + (size_t)r * d->A, logstd + (size_t)r * d->A);
@@ -324,10 +335,11 @@ void orc_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_c
                        const float *returns, const float *old_logp, const float *adv,
                        const int64_t *rows, int n_rows, float inv_B, float *G, double *sums) {
     pol_layout L = policy_layout(d);
-    int O = d->O, H = d->H, A = d->A, nt = L.n_trunks, ct = critic_trunk(d);
-    float *h1 = (float *)malloc(sizeof(float) * nt * H), *h2 = (float *)malloc(sizeof(float) * nt * H);
-    float *dh2 = (float *)calloc((size_t)nt * H, sizeof(float));
-    float *dz = (float *)malloc(sizeof(float) * H), *dh1 = (float *)malloc(sizeof(float) * H);
+    /* activation rows are [n_trunks][S = Hmax]; H stays the ACTOR width (every head but the value head reads actors) */
+    int O = d->O, H = d->H, S = L.Hmax, A = d->A, nt = L.n_trunks, ct = critic_trunk(d);
+    float *h1 = (float *)malloc(sizeof(float) * nt * S), *h2 = (float *)malloc(sizeof(float) * nt * S);
+    float *dh2 = (float *)calloc((size_t)nt * S, sizeof(float));
+    float *dz = (float *)malloc(sizeof(float) * S), *dh1 = (float *)malloc(sizeof(float) * S);
     float *mean = (float *)malloc(sizeof(float) * A), *ls = (float *)malloc(sizeof(float) * A);
     float *dmean = (float *)malloc(sizeof(float) * A), *dls = (float *)malloc(sizeof(float) * A);
     float eps = cfg->clip_param;
@@ -374,9 +386,9 @@ void orc_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_c
             dls[k] = dlogp * (diff * diff / var - 1.0f) - cfg->entropy_coef * inv_B;
         }
         /* heads backward */
-        memset(dh2, 0, sizeof(float) * nt * H);
-        linear_bwd_w(G + L.vw, G + L.vb, &dv, h2 + ct * H, 1, H);
-        linear_bwd_x(P + L.vw, &dv, 1, H, dh2 + ct * H, 1);
+        memset(dh2, 0, sizeof(float) * nt * S);
+        linear_bwd_w(G + L.vw, G + L.vb, &dv, h2 + ct * S, 1, L.Ht[ct]);
+        linear_bwd_x(P + L.vw, &dv, 1, L.Ht[ct], dh2 + ct * S, 1);
         if (d->kind == ORC_KIND_MLP) {
             linear_bwd_w(G + L.mw, G + L.mb, dmean, h2, A, H);
             linear_bwd_x(P + L.mw, dmean, A, H, dh2, 1);
@@ -386,18 +398,19 @@ void orc_ppo_grad_rows(const orc_policy_dims *d, const float *P, const orc_ppo_c
             linear_bwd_x(P + L.cmw, dmean, L.nc, H, dh2, 1);
             linear_bwd_w(G + L.clw, G + L.clb, dls, h2, L.nc, H);
             linear_bwd_x(P + L.clw, dls, L.nc, H, dh2, 1);
-            linear_bwd_w(G + L.amw, G + L.amb, dmean + L.nc, h2 + H, L.na, H);
-            linear_bwd_x(P + L.amw, dmean + L.nc, L.na, H, dh2 + H, 1);
-            linear_bwd_w(G + L.alw, G + L.alb, dls + L.nc, h2 + H, L.na, H);
-            linear_bwd_x(P + L.alw, dls + L.nc, L.na, H, dh2 + H, 1);
+            linear_bwd_w(G + L.amw, G + L.amb, dmean + L.nc, h2 + S, L.na, H);
+            linear_bwd_x(P + L.amw, dmean + L.nc, L.na, H, dh2 + S, 1);
+            linear_bwd_w(G + L.alw, G + L.alb, dls + L.nc, h2 + S, L.na, H);
+            linear_bwd_x(P + L.alw, dls + L.nc, L.na, H, dh2 + S, 1);
         }
         /* trunks backward */
         for (int t = 0; t < nt; ++t) {
-            for (int i = 0; i < H; ++i) dz[i] = dh2[t * H + i] * (1.0f - h2[t * H + i] * h2[t * H + i]);
-            linear_bwd_w(G + L.w2[t], G + L.b2[t], dz, h1 + t * H, H, H);
-            linear_bwd_x(P + L.w2[t], dz, H, H, dh1, 0);
-            for (int i = 0; i < H; ++i) dz[i] = dh1[i] * (1.0f - h1[t * H + i] * h1[t * H + i]);
-            linear_bwd_w(G + L.w1[t], G + L.b1[t], dz, x, H, O);
+            const int Ht = L.Ht[t];
+            for (int i = 0; i < Ht; ++i) dz[i] = dh2[t * S + i] * (1.0f - h2[t * S + i] * h2[t * S + i]);
+            linear_bwd_w(G + L.w2[t], G + L.b2[t], dz, h1 + t * S, Ht, Ht);
+            linear_bwd_x(P + L.w2[t], dz, Ht, Ht, dh1, 0);
+            for (int i = 0; i < Ht; ++i) dz[i] = dh1[i] * (1.0f - h1[t * S + i] * h1[t * S + i]);
+            linear_bwd_w(G + L.w1[t], G + L.b1[t], dz, x, Ht, O);
         }
     }
     free(h1); free(h2); free(dh2); free(dz); free(dh1); free(mean); free(ls); free(dmean); free(dls);

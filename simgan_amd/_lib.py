@@ -48,6 +48,7 @@ PROTOTYPES = {
     "sg_ctx_comm_info": (C.c_int, [H, c_int_p, c_int_p]),
     "sg_ctx_set_disc_dp": (C.c_int, [H, C.c_int]),
     "sg_policy_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
+    "sg_policy_create2": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "sg_policy_destroy": (C.c_int, [H]),
     "sg_policy_num_params": (C.c_int, [H, c_i64_p]),
     "sg_policy_set_params": (C.c_int, [H, c_float_p, C.c_int64]),

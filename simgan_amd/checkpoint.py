@@ -122,9 +122,10 @@ def _policy_dims(class_name, sd):
     if class_name == "Policy":
         H, O = sd["base.actor.0.weight"].shape
         A = sd["dist.fc_mean.weight"].shape[0]
-        assert sd["base.critic.0.weight"].shape == (H, O) and sd["base.critic.2.weight"].shape == (H, H), \
-            "critic trunk differs from the actor's shape (reset_critic with a non-64 hidden size): not representable"
-        return dict(kind="mlp", obs_dim=int(O), act_dim=int(A), hidden=int(H), num_feet=1)
+        Hc = sd["base.critic.0.weight"].shape[0]     # 64 beside any actor width once reset_critic has run (a2c/model.py:80-87)
+        assert sd["base.critic.0.weight"].shape == (Hc, O) and sd["base.critic.2.weight"].shape == (Hc, Hc) and \
+            sd["base.critic_linear.weight"].shape == (1, Hc), "inconsistent critic shapes in the checkpoint"
+        return dict(kind="mlp", obs_dim=int(O), act_dim=int(A), hidden=int(H), num_feet=1, critic_hidden=int(Hc))
     if class_name == "SplitPolicy":
         H, O = sd["base.actor_contact.0.weight"].shape
         f = sd["dist.contact_mean.weight"].shape[0] // 4
@@ -314,7 +315,8 @@ def load_policy(path, ctx=None):
     from .model_split import SplitPolicy
     ck = read_reference_checkpoint(path)
     if ck["kind"] == "mlp":
-        pol = Policy((ck["obs_dim"],), _Box(ck["act_dim"]), base_kwargs={"recurrent": False, "hidden_size": ck["hidden"]}, ctx=ctx)
+        pol = Policy((ck["obs_dim"],), _Box(ck["act_dim"]), base_kwargs={"recurrent": False, "hidden_size": ck["hidden"]}, ctx=ctx,
+                     critic_hidden=ck.get("critic_hidden"))
     else:
         pol = SplitPolicy((ck["obs_dim"],), _Box(ck["act_dim"]),
                           base_kwargs={"hidden_size": ck["hidden"], "num_feet": ck["num_feet"]}, ctx=ctx)

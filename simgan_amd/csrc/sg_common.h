@@ -56,11 +56,13 @@ struct SgTrunk {       // one 2-hidden-layer tanh trunk + its stacked linear hea
     int size;          // block length (floats, multiple of 4)
     int P, Pp, ldP;    // head outputs (real / padded / LDS stride of the [R][Pp] output tile)
     int EX;            // extra per-trunk vector (MLP actor: logstd[A]); 0 if none
+    int H, Hp, ldH;    // this trunk's hidden width (real / padded / LDS stride): the critic's may differ from the actors'
 };
 
 struct SgPolicyDesc {
     int kind, O, A, H, num_feet;
-    int Op, ldO, Hp, ldH;
+    int Hc;               // hidden width of the CRITIC trunk (== H unless Policy.reset_critic rebuilt it: a2c/model.py:80-87)
+    int Op, ldO, Hp, ldH; // Hp / ldH: the WIDEST trunk's (sizes LDS tiles and the row stacks; a trunk computes with its own)
     int n_trunks;         // 2 (MLP: actor, critic) or 3 (split: contact, actuator, critic)
     SgTrunk trunk[3];
     int total;            // padded parameter count
@@ -73,7 +75,7 @@ struct SgDiscDesc {
     int total;
 };
 
-SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet);
+SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet, int Hc = 0);   // Hc 0: critic as wide as the actors
 int64_t sg_policy_flat_count(const SgPolicyDesc& d);
 void sg_policy_pad(const SgPolicyDesc& d, const float* flat, float* padded);    // padded must be zeroed
 void sg_policy_unpad(const SgPolicyDesc& d, const float* padded, float* flat);

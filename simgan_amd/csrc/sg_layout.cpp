@@ -8,8 +8,10 @@
 
 #include "sg_common.h"
 
-static SgTrunk make_trunk(int& cursor, int Hp, int ldO, int ldH, int P, int EX) {
+static SgTrunk make_trunk(int& cursor, int H, int ldO, int P, int EX) {
     SgTrunk t;
+    const int Hp = SG_PAD16(H), ldH = SG_LD(H);
+    t.H = H; t.Hp = Hp; t.ldH = ldH;
     t.off = cursor;
     int o = 0;
     t.w1 = o; o += Hp * ldO;
@@ -28,23 +30,25 @@ static SgTrunk make_trunk(int& cursor, int Hp, int ldO, int ldH, int P, int EX) 
     return t;
 }
 
-SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet) {
+SgPolicyDesc sg_make_policy_desc(int kind, int O, int A, int H, int num_feet, int Hc) {
     SgPolicyDesc d;
     memset(&d, 0, sizeof d);
-    d.kind = kind; d.O = O; d.A = A; d.H = H; d.num_feet = num_feet;
+    if (Hc <= 0) Hc = H;
+    d.kind = kind; d.O = O; d.A = A; d.H = H; d.num_feet = num_feet; d.Hc = Hc;
     d.Op = SG_PAD16(O); d.ldO = SG_LD(O);
-    d.Hp = SG_PAD16(H); d.ldH = SG_LD(H);
+    const int Hmax = H > Hc ? H : Hc;
+    d.Hp = SG_PAD16(Hmax); d.ldH = SG_LD(Hmax);
     int cur = 0;
     if (kind == SG_POLICY_MLP) {
         d.n_trunks = 2;
-        d.trunk[0] = make_trunk(cur, d.Hp, d.ldO, d.ldH, A, A);   // actor: fc_mean head + logstd
-        d.trunk[1] = make_trunk(cur, d.Hp, d.ldO, d.ldH, 1, 0);   // critic: critic_linear head
+        d.trunk[0] = make_trunk(cur, H, d.ldO, A, A);    // actor: fc_mean head + logstd
+        d.trunk[1] = make_trunk(cur, Hc, d.ldO, 1, 0);   // critic: critic_linear head
     } else {
         d.n_trunks = 3;
         d.nc = 4 * num_feet; d.na = 3 * num_feet;
-        d.trunk[0] = make_trunk(cur, d.Hp, d.ldO, d.ldH, 2 * d.nc, 0);  // contact: [mean | logstd]
-        d.trunk[1] = make_trunk(cur, d.Hp, d.ldO, d.ldH, 2 * d.na, 0);  // actuator: [mean | logstd]
-        d.trunk[2] = make_trunk(cur, d.Hp, d.ldO, d.ldH, 1, 0);         // critic_full
+        d.trunk[0] = make_trunk(cur, H, d.ldO, 2 * d.nc, 0);  // contact: [mean | logstd]
+        d.trunk[1] = make_trunk(cur, H, d.ldO, 2 * d.na, 0);  // actuator: [mean | logstd]
+        d.trunk[2] = make_trunk(cur, Hc, d.ldO, 1, 0);        // critic_full
     }
     d.total = cur;
     return d;
@@ -60,29 +64,29 @@ static int64_t policy_segments(const SgPolicyDesc& d, const SegFn& f) {
     auto mat = [&](int64_t po, int rows, int cols, int ld) { f(fo, po, rows, cols, ld); fo += (int64_t)rows * cols; };
     for (int t = 0; t < d.n_trunks; ++t) {
         const SgTrunk& tr = d.trunk[t];
-        mat(tr.off + tr.w1, H, O, d.ldO);
-        mat(tr.off + tr.b1, 1, H, H);
-        mat(tr.off + tr.w2, H, H, d.ldH);
-        mat(tr.off + tr.b2, 1, H, H);
+        mat(tr.off + tr.w1, tr.H, O, d.ldO);
+        mat(tr.off + tr.b1, 1, tr.H, tr.H);
+        mat(tr.off + tr.w2, tr.H, tr.H, tr.ldH);
+        mat(tr.off + tr.b2, 1, tr.H, tr.H);
     }
     const SgTrunk& cr = d.trunk[d.n_trunks - 1];
-    mat(cr.off + cr.wh, 1, H, d.ldH);   // critic_linear / critic_full.4 weight [1,H]
+    mat(cr.off + cr.wh, 1, cr.H, cr.ldH);   // critic_linear / critic_full.4 weight [1, critic width]
     mat(cr.off + cr.bh, 1, 1, 1);
     if (d.kind == SG_POLICY_MLP) {
         const SgTrunk& ac = d.trunk[0];
-        mat(ac.off + ac.wh, A, H, d.ldH);   // fc_mean
+        mat(ac.off + ac.wh, A, H, ac.ldH);   // fc_mean
         mat(ac.off + ac.bh, 1, A, A);
         mat(ac.off + ac.ex, 1, A, A);       // logstd._bias [A,1]
     } else {
         const SgTrunk& c = d.trunk[0];
         const SgTrunk& a = d.trunk[1];
-        mat(c.off + c.wh, d.nc, H, d.ldH);                 // contact_mean
+        mat(c.off + c.wh, d.nc, H, c.ldH);                 // contact_mean
         mat(c.off + c.bh, 1, d.nc, d.nc);
-        mat(a.off + a.wh, d.na, H, d.ldH);                 // actuator_mean
+        mat(a.off + a.wh, d.na, H, a.ldH);                 // actuator_mean
         mat(a.off + a.bh, 1, d.na, d.na);
-        mat(c.off + c.wh + d.nc * d.ldH, d.nc, H, d.ldH);  // contact_logstd -> head rows [nc, 2nc)
+        mat(c.off + c.wh + d.nc * c.ldH, d.nc, H, c.ldH);  // contact_logstd -> head rows [nc, 2nc)
         mat(c.off + c.bh + d.nc, 1, d.nc, d.nc);
-        mat(a.off + a.wh + d.na * d.ldH, d.na, H, d.ldH);  // actuator_logstd -> head rows [na, 2na)
+        mat(a.off + a.wh + d.na * a.ldH, d.na, H, a.ldH);  // actuator_logstd -> head rows [na, 2na)
         mat(a.off + a.bh + d.na, 1, d.na, d.na);
     }
     return fo;

@@ -37,17 +37,17 @@ template <int MT, bool GW = false>
 __device__ __forceinline__ void trunk_forward(const SgPolicyDesc& d, const SgTrunk& tr, const float* W,
                                               const float* X, float* H1, float* H2, float* OUT,
                                               int ldP) {
-    const int ldO = d.ldO, ldH = d.ldH;
+    const int ldO = d.ldO, ldH = tr.ldH, Hp = tr.Hp;   // this trunk's own width (the critic's may differ from the actors')
     const float* b1 = W + tr.b1;
     const float* b2 = W + tr.b2;
     const float* bh = W + tr.bh;
-    sg_layer_nt<MT, GW>(X, ldO, W + tr.w1, ldO, d.Op, d.Hp,
+    sg_layer_nt<MT, GW>(X, ldO, W + tr.w1, ldO, d.Op, Hp,
                         [&](int r, int c, float v) { H1[r * ldH + c] = sg_tanh(v + b1[c]); });
     __syncthreads();
-    sg_layer_nt<MT, GW>(H1, ldH, W + tr.w2, ldH, d.Hp, d.Hp,
+    sg_layer_nt<MT, GW>(H1, ldH, W + tr.w2, ldH, Hp, Hp,
                         [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
     __syncthreads();
-    sg_layer_nt<MT, GW>(H2, ldH, W + tr.wh, ldH, d.Hp, tr.Pp,
+    sg_layer_nt<MT, GW>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp,
                         [&](int r, int c, float v) { OUT[r * ldP + c] = v + bh[c]; });
 }
 
@@ -221,7 +221,13 @@ int sg_policy_forward_device(sg_policy* p, const float* d_obs, int n, int mode, 
 
 extern "C" int sg_policy_create(sg_ctx* ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet,
                                 sg_policy** out) {
+    return sg_policy_create2(ctx, kind, obs_dim, act_dim, hidden, num_feet, 0, out);
+}
+
+extern "C" int sg_policy_create2(sg_ctx* ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet, int critic_hidden,
+                                 sg_policy** out) {
     SG_REQUIRE(ctx && out, "sg_policy_create: NULL argument");
+    SG_REQUIRE(critic_hidden >= 0, "sg_policy_create2: bad critic_hidden");
     SG_REQUIRE(kind == SG_POLICY_MLP || kind == SG_POLICY_SPLIT, "sg_policy_create: unknown kind %d", kind);
     SG_REQUIRE(obs_dim > 0 && act_dim > 0 && hidden > 0, "sg_policy_create: bad dims");
     if (kind == SG_POLICY_SPLIT)
@@ -230,7 +236,7 @@ extern "C" int sg_policy_create(sg_ctx* ctx, int kind, int obs_dim, int act_dim,
     SG_CHECK(hipSetDevice(ctx->device));
     sg_policy* p = new sg_policy();
     p->ctx = ctx;
-    p->desc = sg_make_policy_desc(kind, obs_dim, act_dim, hidden, num_feet);
+    p->desc = sg_make_policy_desc(kind, obs_dim, act_dim, hidden, num_feet, critic_hidden);
     // any width the reference's constructor accepts (a2c/arguments.py:107-109, a2c/model.py:233-253): a trunk that fits a
     // CU's LDS runs on the LDS-resident kernels, a larger one on the global-weight instances; only one 16-row activation
     // tile has to fit
@@ -456,7 +462,7 @@ extern "C" int sg_policy_act_ensemble(sg_policy* const* policies, int n_policies
     for (int k = 0; k < n_policies; ++k) {
         SG_REQUIRE(policies[k] && policies[k]->ctx == ctx, "sg_policy_act_ensemble: member %d is NULL or lives on another context", k);
         const SgPolicyDesc& e = policies[k]->desc;
-        SG_REQUIRE(e.kind == d.kind && e.O == d.O && e.A == d.A && e.H == d.H && e.num_feet == d.num_feet,
+        SG_REQUIRE(e.kind == d.kind && e.O == d.O && e.A == d.A && e.H == d.H && e.Hc == d.Hc && e.num_feet == d.num_feet,
                    "sg_policy_act_ensemble: member %d has a different shape", k);
         a.params[k] = policies[k]->d_params;
     }

@@ -78,8 +78,10 @@ static int ppo_block_threads(int MT) {
     return (MT >= 2 && !(we && atoi(we) == 4)) ? 512 : 256;
 }
 
+// (the shape-specialised instances fold ONE hidden width into the code: a policy whose critic was rebuilt at another width
+// -- Policy.reset_critic, d.Hc != d.H -- takes the run-time-shape instances, kh = 0 matches none of them)
 static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool gw) {
-    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const int ko = d.Op / 16, kh = d.Hc == d.H ? d.Hp / 16 : 0;
     const dim3 block(ppo_block_threads(MT));
     if (gw) {   // general-shape instances: run-time extents, weights through L2
         if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<2, 0, 0, true>), grid, block, lds, pa);
@@ -95,7 +97,7 @@ static void launch_ppo_fwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd<1, 0, 0>), grid, block, lds, pa);
 }
 static void launch_ppo_fwd_critic(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa) {
-    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const int ko = d.Op / 16, kh = d.Hc == d.H ? d.Hp / 16 : 0;
     const dim3 block(ppo_block_threads(MT));
     if (MT == 2 && ko == 4 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 4, 7>), grid, block, lds, pa); return; }   // LaikagoCombined
     if (MT == 2 && ko == 1 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 1, 7>), grid, block, lds, pa); return; }   // HopperCombined
@@ -103,7 +105,7 @@ static void launch_ppo_fwd_critic(sg_ctx* ctx, int MT, const SgPolicyDesc& d, di
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<1, 0, 0>), grid, block, lds, pa);
 }
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused, bool gw) {
-    const int ko = d.Op / 16, kh = d.Hp / 16;
+    const int ko = d.Op / 16, kh = d.Hc == d.H ? d.Hp / 16 : 0;
     const dim3 block(ppo_block_threads(MT));
     if (gw) {
         if (fused && MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_bwd<2, 0, 0, true, true>), grid, block, lds, pa);

@@ -109,9 +109,10 @@ __device__ __forceinline__ void sg_ppo_fwd_body(const PpoArgs& a, const int t, c
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
     const SgPolicyDesc& d = a.d;
-    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
     const int tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
+    // (run-time instances: the trunk's OWN hidden width -- a critic rebuilt by Policy.reset_critic differs from the actors)
+    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : tr.Hp;
     const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP;
     const float* W = GW ? a.params + tr.off : smem;
     float* X = smem + a.wbuf_floats;
@@ -179,9 +180,9 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     // the descriptor is read in place (a modified local copy indexed by blockIdx.y would live in scratch memory);
     // with compile-time KO/KH the four extents below fold to constants
     const SgPolicyDesc& d = a.d;
-    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : d.Hp;
     const int tid = threadIdx.x;
     const SgTrunk tr = d.trunk[t];
+    const int Op = (KO > 0 && KH > 0) ? 16 * KO : d.Op, Hp = (KO > 0 && KH > 0) ? 16 * KH : tr.Hp;   // the trunk's own width
     const bool critic = t == d.n_trunks - 1;
     const bool mlp = d.kind == SG_POLICY_MLP;
     const int ldO = Op + 4, ldH = Hp + 4, ldP = a.ldP, A = d.A;

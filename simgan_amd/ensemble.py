@@ -19,7 +19,7 @@ class PolicyEnsemble(object):
     def __init__(self, policies, seed=0):
         assert 0 < len(policies) <= 8, "1..8 ensemble members (SG_ENSEMBLE_MAX)"
         self.policies = list(policies)
-        shapes = {(type(p), p.obs_dim, p.act_dim, p.hidden_size, p.num_feet) for p in self.policies}
+        shapes = {(type(p), p.obs_dim, p.act_dim, p.hidden_size, p.critic_hidden, p.num_feet) for p in self.policies}
         assert len(shapes) == 1, "ensemble members must share kind, observation, action and hidden sizes"
         self.obs_dim, self.act_dim = self.policies[0].obs_dim, self.policies[0].act_dim
         self.lib = self.policies[0].lib

@@ -19,14 +19,16 @@ MATERIALISE_CTX = None
 class _PolicyBase(object):
     KIND = None
 
-    def _create(self, obs_dim, act_dim, hidden, num_feet, ctx):
+    def _create(self, obs_dim, act_dim, hidden, num_feet, ctx, critic_hidden=None):
         self.ctx = ctx or _lib.Context.default()
         self.lib = self.ctx.lib
         self.obs_dim, self.act_dim = int(obs_dim), int(act_dim)
         self.hidden_size, self.num_feet = int(hidden), int(num_feet)
+        # width of the critic trunk: the actors' unless reset_critic rebuilt it (a2c/model.py:80-87: always 64 units)
+        self.critic_hidden = int(critic_hidden) if critic_hidden else self.hidden_size
         h = _lib.H()
-        _lib.check(self.lib.sg_policy_create(self.ctx.h, self.KIND, self.obs_dim, self.act_dim,
-                                             self.hidden_size, self.num_feet, C.byref(h)))
+        _lib.check(self.lib.sg_policy_create2(self.ctx.h, self.KIND, self.obs_dim, self.act_dim, self.hidden_size, self.num_feet,
+                                              0 if self.critic_hidden == self.hidden_size else self.critic_hidden, C.byref(h)))
         self.h = h
         n = C.c_int64(0)
         _lib.check(self.lib.sg_policy_num_params(self.h, C.byref(n)))
@@ -58,7 +60,8 @@ class _PolicyBase(object):
             dims, sd = policy_from_module_state(type(self).__name__, st)
             # the context an unpickled policy lands on: `simgan_amd.model.MATERIALISE_CTX` when the caller set one,
             # the process default otherwise (see the module-level comment)
-            self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], MATERIALISE_CTX)
+            self._create(dims["obs_dim"], dims["act_dim"], dims["hidden"], dims["num_feet"], MATERIALISE_CTX,
+                         critic_hidden=dims.get("critic_hidden"))
             self.seed = derive_seed(0, 0x5EED, per_instance=True)
             self.load_state_dict(sd)
         except BaseException:
@@ -123,7 +126,7 @@ class _PolicyBase(object):
 
     def __getstate__(self):
         return {"obs_dim": self.obs_dim, "act_dim": self.act_dim, "hidden": self.hidden_size,
-                "num_feet": self.num_feet, "flat": self.get_flat_params()}
+                "num_feet": self.num_feet, "critic_hidden": self.critic_hidden, "flat": self.get_flat_params()}
 
     def __setstate__(self, st):
         if "_modules" in st:   # a reference whole-module pickle (a2c/main.py:81-83) resolved to this class by the alias modules.
@@ -131,7 +134,7 @@ class _PolicyBase(object):
             # weights are read when the policy is first used, not here.
             self.__dict__["_pending"] = st
             return
-        self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None)
+        self._create(st["obs_dim"], st["act_dim"], st["hidden"], st["num_feet"], None, critic_hidden=st.get("critic_hidden"))
         self.seed = derive_seed(0, 0x5EED, per_instance=True)
         self.set_flat_params(st["flat"])
 
@@ -176,7 +179,7 @@ class _PolicyBase(object):
 class Policy(_PolicyBase):
     KIND = _lib.POLICY_MLP
 
-    def __init__(self, obs_shape, action_space, base=None, base_kwargs=None, ctx=None, seed=0):
+    def __init__(self, obs_shape, action_space, base=None, base_kwargs=None, ctx=None, seed=0, critic_hidden=None):
         if base_kwargs is None:
             base_kwargs = {}
         if base is not None or len(obs_shape) != 1:
@@ -186,17 +189,17 @@ class Policy(_PolicyBase):
         if action_space.__class__.__name__ != "Box":
             raise NotImplementedError("only Box action spaces (a2c/model.py:55-57)")
         hidden = base_kwargs.get("hidden_size", 64)
-        self._create(obs_shape[0], action_space.shape[0], hidden, 1, ctx)
+        self._create(obs_shape[0], action_space.shape[0], hidden, 1, ctx, critic_hidden=critic_hidden)
         self.seed = derive_seed(seed, 0x5EED, per_instance=True)
         self._init_params(np.random.default_rng(seed))
 
     def param_shapes(self):
-        O, A, Hh = self.obs_dim, self.act_dim, self.hidden_size
+        O, A, Hh, Hc = self.obs_dim, self.act_dim, self.hidden_size, self.critic_hidden
         return [("base.actor.0.weight", (Hh, O)), ("base.actor.0.bias", (Hh,)),
                 ("base.actor.2.weight", (Hh, Hh)), ("base.actor.2.bias", (Hh,)),
-                ("base.critic.0.weight", (Hh, O)), ("base.critic.0.bias", (Hh,)),
-                ("base.critic.2.weight", (Hh, Hh)), ("base.critic.2.bias", (Hh,)),
-                ("base.critic_linear.weight", (1, Hh)), ("base.critic_linear.bias", (1,)),
+                ("base.critic.0.weight", (Hc, O)), ("base.critic.0.bias", (Hc,)),
+                ("base.critic.2.weight", (Hc, Hc)), ("base.critic.2.bias", (Hc,)),
+                ("base.critic_linear.weight", (1, Hc)), ("base.critic_linear.bias", (1,)),
                 ("dist.fc_mean.weight", (A, Hh)), ("dist.fc_mean.bias", (A,)),
                 ("dist.logstd._bias", (A, 1))]
 
@@ -222,17 +225,19 @@ class Policy(_PolicyBase):
         self.load_state_dict(sd)
 
     def reset_critic(self, obs_shape, seed=1):
-        """a2c/model.py:80-87: fresh orthogonal critic trunk + value head, zero biases.  The reference hard-codes a
-        64-unit critic whatever the actor's width; this library keeps ONE hidden size per policy, so the call is
-        only accepted where both agree (hidden_size == 64: every shipped config that warm-starts,
-        train_laika_power.sh:7) and raises otherwise instead of silently building a different network."""
-        if self.hidden_size != 64:
-            raise NotImplementedError("reset_critic: the reference rebuilds a 64-unit critic (a2c/model.py:84-86); "
-                                      f"this policy has hidden_size={self.hidden_size}")
+        """a2c/model.py:80-87: a fresh critic -- Linear(obs, 64)-Tanh-Linear(64, 64)-Tanh + Linear(64, 1), orthogonal with gain
+        sqrt 2, zero biases -- whatever the actor's width ("64" is hard-coded in the reference; a2c/main.py:85 calls this on
+        every warm start).  When the actor is not 64 wide the policy is rebuilt on the device with a critic trunk of its own
+        width (sg_policy_create2); actor, mean head and log-std keep their values.  Call it BEFORE constructing PPO on this
+        policy, as the reference's main does (:85 then :149): an agent built earlier holds the old device handle."""
         if int(obs_shape[0]) != self.obs_dim:
             raise ValueError(f"reset_critic: obs_shape {tuple(obs_shape)} != the policy's observation size {self.obs_dim}")
         rng = np.random.default_rng(seed)
         sd = self.state_dict()
+        if self.critic_hidden != 64:
+            old = self.h
+            self._create(self.obs_dim, self.act_dim, self.hidden_size, self.num_feet, self.ctx, critic_hidden=64)
+            self.lib.sg_policy_destroy(old)
         for name, shape in self.param_shapes():
             if name.startswith("base.critic"):
                 sd[name] = (np.zeros(shape, np.float32) if name.endswith("bias")

@@ -567,26 +567,32 @@ def test_full_iteration_golden(sg, name):
 
 
 # ------------------------------------------------------- the plain-PPO caller (a2c/main.py), BASELINE.json configs[4]
-def test_refine_iteration_golden(sg):
+@pytest.mark.parametrize("fixture", ["iter_refine", "iter_refine_h100"])
+def test_refine_iteration_golden(sg, fixture):
     """a2c/main.py:78-88,199-257 through driver.PpoLearner: warm start from a reference-written checkpoint, reset_critic,
     reset_variance, linear LR decay, two outer iterations at the Laikago refinement shape (obs 111, act 12, h64,
-    num_mini_batch 8, clip 0.1, lr 1.5e-4) with the reference's noise / permutations injected."""
+    num_mini_batch 8, clip 0.1, lr 1.5e-4) with the reference's noise / permutations injected -- and the same from a
+    100-unit behaviour policy, where reset_critic leaves a 64-unit critic beside the 100-unit actor (a2c/model.py:80-87)."""
     import os
 
     from helpers import GOLDEN
     from simgan_amd.driver import PpoLearner
-    g = load("iter_refine")
+    g = load(fixture)
     m = g["meta"]
     T, N, O, A, H = m["T"], m["N"], m["O"], m["A"], m["H"]
-    p = PpoLearner.warm_start(os.path.join(GOLDEN, "iter_refine_warm.pt"), (O,), Box((A,)), warm_start_logstd=m["warm_start_logstd"])
+    Hc = 64
+    p = PpoLearner.warm_start(os.path.join(GOLDEN, fixture + "_warm.pt"), (O,), Box((A,)), warm_start_logstd=m["warm_start_logstd"])
+    assert p.hidden_size == H and p.critic_hidden == Hc
     flat = p.get_flat_params()
-    na, nc = H * O + H + H * H + H, H * O + H + H * H + H + H + 1
+    assert flat.size == g["pi_params0"].size
+    na = H * O + H + H * H + H
+    nc, nc_beh = Hc * O + Hc + Hc * Hc + Hc + Hc + 1, H * O + H + H * H + H + H + 1
     assert np.array_equal(flat[:na], g["behaviour_params"][:na])                       # actor kept
-    assert np.array_equal(flat[na + nc:-A], g["behaviour_params"][na + nc:-A])         # mean head kept
+    assert np.array_equal(flat[na + nc:-A], g["behaviour_params"][na + nc_beh:-A])     # mean head kept
     assert np.all(flat[-A:] == np.float32(m["warm_start_logstd"]))                     # reset_variance
-    W1c = flat[na:na + H * O].reshape(H, O)                                            # reset_critic: orthogonal rows, gain sqrt2
-    assert_close(W1c @ W1c.T, 2.0 * np.eye(H), rtol=0, atol=1e-5, what="critic.0 orthogonal init")
-    assert np.all(flat[na + H * O:na + H * O + H] == 0) and not np.array_equal(W1c.reshape(-1), g["behaviour_params"][na:na + H * O])
+    W1c = flat[na:na + Hc * O].reshape(Hc, O)                                          # reset_critic: orthogonal, gain sqrt2
+    assert_close(W1c @ W1c.T if Hc <= O else W1c.T @ W1c, 2.0 * np.eye(min(Hc, O)), rtol=0, atol=1e-5, what="critic.0 orthogonal init")
+    assert np.all(flat[na + Hc * O:na + Hc * O + Hc] == 0)
     p.set_flat_params(g["pi_params0"])      # the critic draw itself is torch-RNG specific: continue from the reference's
     agent = sg.algo.PPO(p, m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], 0.5, 0.0, lr=m["lr"], eps=1e-5, max_grad_norm=0.5)
     ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, O)
@@ -625,8 +631,14 @@ def test_refine_iteration_golden(sg):
         assert_close(ro.returns.numpy()[:T], g[f"it{j}_returns"][:T], what="returns")
         assert_close([out["value_loss"], out["action_loss"], out["dist_entropy"]], g[f"it{j}_ppo_losses"], what="ppo losses")
         assert_close(p.get_flat_params(), g[f"it{j}_pi_params"], what="pi params")
-    with pytest.raises(NotImplementedError):   # the reference's reset_critic builds a 64-unit critic whatever the actor is
-        sg.Policy((5,), Box((2,)), base_kwargs={"hidden_size": 32}).reset_critic((5,))
+    # the reference's reset_critic builds a 64-unit critic whatever the actor is: so does the shim, on a fresh device handle
+    q = sg.Policy((5,), Box((2,)), base_kwargs={"hidden_size": 32})
+    n0 = q.num_params
+    q.reset_critic((5,))
+    assert q.critic_hidden == 64 and q.hidden_size == 32 and q.num_params == n0 - (32 * 5 + 32 + 32 * 32 + 32 + 32 + 1) + (64 * 5 + 64 + 64 * 64 + 64 + 64 + 1)
+    import pickle
+    q2 = pickle.loads(pickle.dumps(q))          # survives the package's own pickle with its critic width
+    assert q2.critic_hidden == 64 and np.array_equal(q2.get_flat_params(), q.get_flat_params())
 
 
 def test_collect_then_update_device_resident_equals_drop_in(sg):

@@ -223,22 +223,30 @@ def test_full_iteration(name):
         obs[0], obs_feat[0], masks[0], bad[0] = obs[T], obs_feat[T], masks[T], bad[T]
 
 
-def test_refine_iteration():
+@pytest.mark.parametrize("fixture", ["iter_refine", "iter_refine_h100"])
+def test_refine_iteration(fixture):
     """a2c/main.py:199-257 (policy refinement: warm start, reset critic / variance, linear LR decay, no D) restated
-    with oracle calls: 2 outer iterations at the Laikago refinement shape (obs 111, act 12, h64, 8 minibatches, clip 0.1)."""
-    g = load("iter_refine")
+    with oracle calls: 2 outer iterations at the Laikago refinement shape (obs 111, act 12, h64, 8 minibatches, clip 0.1), and
+    from a 100-unit behaviour policy, where reset_critic leaves a 64-unit critic beside the 100-unit actor
+    (a2c/model.py:80-87 hard-codes 64)."""
+    g = load(fixture)
     m = g["meta"]
-    d = dims_of(m)
     T, N, O, A, H = m["T"], m["N"], m["O"], m["A"], m["H"]
+    Hc = 64                                         # the reference's reset_critic
+    d = orc.dims(KIND[m["kind"]], O, A, H, m["num_feet"], Hc)
     pi = g["pi_params0"].copy()
+    assert pi.size == orc.policy_num_params(d)
     # warm start keeps the actor and the mean head, re-draws the critic (zero biases), resets logstd (a2c/main.py:85-87)
     beh = g["behaviour_params"]
     na = H * O + H + H * H + H                      # base.actor.*
-    nc = na + 1 * H + 1                             # base.critic.* + critic_linear
-    assert np.array_equal(pi[:na], beh[:na]) and not np.array_equal(pi[na:na + H * O], beh[na:na + H * O])
-    assert np.array_equal(pi[na + nc:na + nc + A * H + A], beh[na + nc:na + nc + A * H + A])
+    nc = Hc * O + Hc + Hc * Hc + Hc + Hc + 1        # base.critic.* + critic_linear, 64 wide after the reset
+    nc_beh = H * O + H + H * H + H + H + 1          # ... and as wide as the actor in the behaviour policy
+    assert np.array_equal(pi[:na], beh[:na])
+    assert np.array_equal(pi[na + nc:na + nc + A * H + A], beh[na + nc_beh:na + nc_beh + A * H + A])
     assert np.all(pi[-A:] == np.float32(m["warm_start_logstd"]))
-    assert np.all(pi[na + H * O:na + H * O + H] == 0) and pi[na + nc - 1] == 0
+    assert np.all(pi[na + Hc * O:na + Hc * O + Hc] == 0) and pi[na + nc - 1] == 0
+    W1c = pi[na:na + Hc * O].reshape(Hc, O)
+    assert_close((W1c @ W1c.T if Hc <= O else W1c.T @ W1c), 2.0 * np.eye(min(Hc, O)), rtol=0, atol=1e-5, what="critic.0 orthogonal, gain sqrt 2")
     adam = orc.AdamState(pi.size)
     obs = np.zeros((T + 1, N, O), np.float32)
     masks, bad = np.ones((T + 1, N), np.float32), np.ones((T + 1, N), np.float32)
@@ -271,11 +279,11 @@ def test_refine_iteration():
 # ---------------------------------------------------------------------------------------------------------------------
 # oracle/sg_cpu_fast.c -- the batched, vectorised CPU implementation bench.py times as `cpu_baseline` -- against the
 # oracle: same gradients and loss sums at the suite's tolerance, for both policy kinds and the discriminator.
-@pytest.mark.parametrize("kind,O,A,H,f", [("mlp", 47, 12, 64, 1), ("mlp", 11, 3, 64, 1), ("split", 14, 7, 100, 1), ("split", 64, 28, 100, 4),
-                                          ("mlp", 5, 2, 7, 1)])
-def test_fast_cpu_ppo_gradient_equals_the_oracle(kind, O, A, H, f):
+@pytest.mark.parametrize("kind,O,A,H,f,Hc", [("mlp", 47, 12, 64, 1, 0), ("mlp", 11, 3, 64, 1, 0), ("split", 14, 7, 100, 1, 0),
+                                             ("split", 64, 28, 100, 4, 0), ("mlp", 5, 2, 7, 1, 0), ("mlp", 20, 5, 100, 1, 64), ("mlp", 9, 4, 24, 1, 64)])
+def test_fast_cpu_ppo_gradient_equals_the_oracle(kind, O, A, H, f, Hc):
     rng = np.random.default_rng(O * 100 + H)
-    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f)
+    d = orc.dims(orc.KIND_MLP if kind == "mlp" else orc.KIND_SPLIT, O, A, H, f, Hc)
     n = 203                                      # not a multiple of the 4-row panels
     # (a state-dependent log-std head on N(0, 0.15) weights gives log-probs of -1000 and sums that cancel to 1e-4 of their terms)
     par = (rng.standard_normal(orc.policy_num_params(d)) * (0.15 if kind == "mlp" else 0.05)).astype(np.float32)

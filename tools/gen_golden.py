@@ -630,6 +630,11 @@ if __name__ == "__main__":
             if what == "refine":
                 gen_refine("iter_refine", O=111, A=12, H=64, T=8, N=16, E=2, M=8, clip=0.1, lr=1.5e-4, num_updates=4, iters=2,
                            logstd=-1.3, seed=600)
+            elif what == "refine_h100":
+                # the same loop from a 100-unit behaviour policy: reset_critic then leaves a 64-unit critic beside the
+                # 100-unit actor (a2c/model.py:80-87 hard-codes 64)
+                gen_refine("iter_refine_h100", O=20, A=5, H=100, T=8, N=16, E=2, M=4, clip=0.1, lr=1.5e-4, num_updates=4, iters=2,
+                           logstd=-1.3, seed=650)
             elif what == "vecnormalize":
                 gen_vecnormalize()
             elif what == "checkpoints":
@@ -665,6 +670,7 @@ if __name__ == "__main__":
     gen_checkpoints()
     gen_iteration("iter_split", "split", 14, 7, 100, 1, F=25, Hd=100, T=8, N=16, B=32, Ne=100, E=2, M=2, Ed=2, iters=2, seed=510)
     gen_refine("iter_refine", O=111, A=12, H=64, T=8, N=16, E=2, M=8, clip=0.1, lr=1.5e-4, num_updates=4, iters=2, logstd=-1.3, seed=600)
+    gen_refine("iter_refine_h100", O=20, A=5, H=100, T=8, N=16, E=2, M=4, clip=0.1, lr=1.5e-4, num_updates=4, iters=2, logstd=-1.3, seed=650)
     gen_vecnormalize()
     gen_ffgen()
     gen_predict_reward()
