@@ -300,6 +300,66 @@ def save_reference_checkpoint(path, kind, state_dict, ob_rms=None):
             torch.save([pol, rms], path, _use_new_zipfile_serialization=False)
 
 
+# ------------------------------------------------------------ torch.save of a shim policy, as the unchanged mains call it
+def _module_state(**extra):
+    """A fresh torch.nn.Module's `__dict__` (whatever this torch version keeps in it) with private containers."""
+    import torch
+    d = {}
+    for k, v in torch.nn.Module().__dict__.items():
+        d[k] = type(v)() if isinstance(v, (dict, set, list)) else v
+    d.update(extra)
+    return d
+
+
+def _holder(module, name, modules=(), params=(), **attrs):
+    """An instance of the alias package's holder class `third_party.a2c_ppo_acktr.<module>.<name>` carrying an
+    nn.Module-shaped `__dict__`: pickled by reference to that path, it is what the REFERENCE's class of the same name
+    receives in `__setstate__` on the loading side."""
+    import importlib
+    cls = getattr(importlib.import_module(f"{REF_PKG}.{module}"), name)
+    h = cls.__new__(cls)
+    st = _module_state(**attrs)
+    for k, v in modules:
+        st["_modules"][k] = v
+    for k, v in params:
+        st["_parameters"][k] = v
+    h.__dict__.update(st)
+    return h
+
+
+def reference_module_state(kind, sd):
+    """The `__dict__` the reference's `Policy` / `SplitPolicy` module would pickle for the parameters `sd` (name -> array,
+    the reference's parameter names): `_modules = {base, dist}` with real torch.nn layers inside holder objects whose
+    classes live at the reference's import paths.  `simgan_amd.model._PolicyBase.__reduce_ex__` returns it when the policy
+    was built through `third_party.a2c_ppo_acktr.model[_split]` -- i.e. by the unchanged mains -- so the file their
+    `torch.save([actor_critic, ob_rms], path)` writes (a2c/main_gail_dyn_ppo.py:307-316, a2c/main.py:260-269) is one the
+    REFERENCE's `torch.load` turns back into its own modules: the stage-2 environment workers load five of them on the
+    CPU (my_pybullet_envs/utils.py:24-57, hopper_env_combined_policy.py:113-140), with no GPU and without this package."""
+    import torch
+    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, np.float32) for k, v in sd.items()}
+    if kind == "mlp":
+        base = _holder("model", "MLPBase", modules=[("actor", _trunk(sd, "base.actor")), ("critic", _trunk(sd, "base.critic")),
+                                                    ("critic_linear", _linear(sd["base.critic_linear.weight"], sd["base.critic_linear.bias"]))],
+                       _hidden_size=int(sd["base.actor.0.weight"].shape[0]), _recurrent=False)
+        bias = _holder("utils", "AddBias", params=[("_bias", torch.nn.Parameter(torch.from_numpy(sd["dist.logstd._bias"].reshape(-1, 1).copy())))])
+        dist = _holder("distributions", "DiagGaussian", modules=[("fc_mean", _linear(sd["dist.fc_mean.weight"], sd["dist.fc_mean.bias"])),
+                                                                 ("logstd", bias)])
+    elif kind == "split":
+        base = _holder("model_split", "SplitPolicyBaseNew", modules=[("actor_contact", _trunk(sd, "base.actor_contact")),
+                                                                     ("actor_actuator", _trunk(sd, "base.actor_actuator")),
+                                                                     ("critic_full", _trunk(sd, "base.critic_full", head=True))])
+        dist = _holder("model_split", "StateDiagGaussianNew",
+                       modules=[(h, _linear(sd[f"dist.{h}.weight"], sd[f"dist.{h}.bias"])) for h in
+                                ("contact_mean", "actuator_mean", "contact_logstd", "actuator_logstd")],
+                       hidden_size=int(sd["base.actor_contact.0.weight"].shape[0]))      # a2c/model_split.py:204
+    else:
+        raise ValueError(kind)
+    st = _module_state()
+    st["_modules"]["base"] = base
+    st["_modules"]["dist"] = dist
+    return st
+
+
 # ---------------------------------------------------------------------------------- device wrappers
 class _Box(object):
     def __init__(self, n):

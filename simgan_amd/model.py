@@ -128,6 +128,18 @@ class _PolicyBase(object):
         return {"obs_dim": self.obs_dim, "act_dim": self.act_dim, "hidden": self.hidden_size,
                 "num_feet": self.num_feet, "critic_hidden": self.critic_hidden, "flat": self.get_flat_params()}
 
+    def __reduce_ex__(self, protocol):
+        """A policy built through the reference's import path (`third_party.a2c_ppo_acktr.model[_split]`, i.e. by the
+        unchanged mains) pickles in the REFERENCE's object layout: what their `torch.save([actor_critic, ob_rms], path)`
+        writes is then a file the reference itself loads -- on the CPU, without this package (the stage-2 environment
+        workers do, my_pybullet_envs/utils.py:24-57).  Loading it here goes through `__setstate__`'s "_modules" branch like
+        any reference checkpoint.  The package's own classes keep their compact native pickle."""
+        if type(self).__module__.startswith("third_party."):
+            import copyreg
+            from .checkpoint import reference_module_state
+            return (copyreg.__newobj__, (type(self),), reference_module_state("mlp" if self.KIND == _lib.POLICY_MLP else "split", self.state_dict()))
+        return object.__reduce_ex__(self, protocol)
+
     def __setstate__(self, st):
         if "_modules" in st:   # a reference whole-module pickle (a2c/main.py:81-83) resolved to this class by the alias modules.
             # torch's legacy container fills the tensors' storages only AFTER the whole object graph is unpickled, so the

@@ -757,7 +757,7 @@ def test_bare_torch_load_through_alias_modules_gives_the_shim(sg):
         "for name in ('ckpt_policy_mlp', 'ckpt_policy_split'):\n"
         "    g = load(name)\n"
         "    actor_critic, ob_rms = torch.load(%r + '/' + name + '.pt', map_location='cpu', weights_only=False)\n"
-        "    assert type(actor_critic) in (sg.Policy, sg.SplitPolicy), type(actor_critic)\n"
+        "    assert isinstance(actor_critic, (sg.Policy, sg.SplitPolicy)), type(actor_critic)\n"
         "    assert np.array_equal(actor_critic.get_flat_params(), g['flat'])\n"
         "    v, a, lp, _ = actor_critic.act(torch.from_numpy(g['obs']), None, None, deterministic=True)\n"
         "    assert_close(a, g['action'], what='action'); assert_close(v, g['value'], what='value')\n"
@@ -766,6 +766,46 @@ def test_bare_torch_load_through_alias_modules_gives_the_shim(sg):
         "print('ok')\n") % (os.path.join(root, "tests"), GOLDEN)
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_torch_save_by_the_unchanged_main_writes_the_reference_layout(sg, tmp_path):
+    """a2c/main_gail_dyn_ppo.py:307-316: `torch.save([actor_critic, ob_rms], path)` on policies built through the
+    reference's import path.  The file names only the reference's classes (tests/test_interop.py loads such a file with the
+    reference alone, in the dev container); reloaded with a bare torch.load it is a device-backed policy with the same
+    weights and outputs; a policy built from `simgan_amd` directly keeps the package's compact pickle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch, pickle\n"
+        "import simgan_amd as sg\n"
+        "from simgan_amd import checkpoint as ck\n"
+        "from third_party.a2c_ppo_acktr.model import Policy\n"
+        "from third_party.a2c_ppo_acktr.model_split import SplitPolicy\n"
+        "class Box:\n"
+        "    def __init__(self, s): self.shape = s\n"
+        "for pol in (Policy((11,), Box((3,)), base_kwargs={'recurrent': False, 'hidden_size': 64}),\n"
+        "            SplitPolicy((14,), Box((7,)), base_kwargs={'hidden_size': 100, 'num_feet': 1}),\n"
+        "            Policy((9,), Box((4,)), base_kwargs={'recurrent': False, 'hidden_size': 32})):\n"
+        "    if pol.hidden_size == 32: pol.reset_critic((9,))      # 64-unit critic beside a 32-unit actor\n"
+        "    path = sys.argv[1] + '/p.pt'\n"
+        "    torch.save([pol, None], path)                         # exactly the main's call\n"
+        "    c = ck.read_reference_checkpoint(path)                # parsed with inert stand-ins: the reference's layout\n"
+        "    assert np.array_equal(np.concatenate([v.reshape(-1) for v in c['state_dict'].values()]), pol.get_flat_params())\n"
+        "    assert c['class_name'] == type(pol).__name__ and c['hidden'] == pol.hidden_size\n"
+        "    back, rms = torch.load(path, map_location='cpu', weights_only=False)\n"
+        "    assert type(back) is type(pol) and rms is None and back.critic_hidden == pol.critic_hidden\n"
+        "    obs = np.random.default_rng(0).standard_normal((5, pol.obs_dim)).astype(np.float32)\n"
+        "    a0 = pol.act(obs, None, None, deterministic=True); a1 = back.act(obs, None, None, deterministic=True)\n"
+        "    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a0[:3], a1[:3]))\n"
+        "native = sg.Policy((11,), Box((3,)), base_kwargs={'recurrent': False, 'hidden_size': 64})\n"
+        "n2 = pickle.loads(pickle.dumps(native))\n"
+        "assert type(n2) is sg.Policy and np.array_equal(n2.get_flat_params(), native.get_flat_params())\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
 
 

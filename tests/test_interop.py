@@ -137,3 +137,74 @@ def test_expert_loader_handles_state_and_action_of_different_width_and_subsets()
     assert ex.load_sas_wpast_from_pickle(trajs, load_num_trajs=2)[0].shape == (9, 5)
     sub = ex.load_sas_wpast_from_pickle(trajs, downsample_freq=3, start_idx=[0, 1, 2])
     assert sub[0].shape[0] == len(range(0, 4, 3)) + len(range(1, 5, 3)) + len(range(2, 6, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `torch.save([actor_critic, ob_rms], path)` as the UNCHANGED mains call it (a2c/main_gail_dyn_ppo.py:307-316) on a policy
+# they built through `third_party.a2c_ppo_acktr.model[_split]`: the file must be the reference's object layout, loadable
+# by the reference alone (the stage-2 environment workers `torch.load` five of them on the CPU,
+# my_pybullet_envs/utils.py:24-57).  Device-less here: the weights come from a fixture instead of HBM.
+_WRITE_THROUGH_THE_ALIAS = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {tests!r})
+from helpers import load
+name, out = sys.argv[1], sys.argv[2]
+g = load(name)
+m = g["meta"]
+if m["kind"] == "mlp":
+    from third_party.a2c_ppo_acktr.model import Policy as Cls
+else:
+    from third_party.a2c_ppo_acktr.model_split import SplitPolicy as Cls
+p = Cls.__new__(Cls)                                    # no device in this container: the shim's host half only
+p.__dict__.update(obs_dim=m["O"], act_dim=m["A"], hidden_size=m["H"], critic_hidden=m["H"], num_feet=m["f"])
+sd, off = {{}}, 0
+for k, shape in p.param_shapes():
+    n = int(np.prod(shape)); sd[k] = g["flat"][off:off + n].reshape(shape); off += n
+p.state_dict = lambda: sd
+torch.save([p, None], out)
+import pickletools, zipfile, io
+blob = open(out, "rb").read()
+data = zipfile.ZipFile(out).read([n for n in zipfile.ZipFile(out).namelist() if n.endswith("data.pkl")][0]) if zipfile.is_zipfile(out) else blob
+names = {{(a if isinstance(a, str) else "") for op, a, _ in pickletools.genops(data) if op.name in ("GLOBAL", "STACK_GLOBAL", "SHORT_BINUNICODE", "BINUNICODE")}}
+assert not [s for s in names if "simgan_amd" in s], "the file must not name this package"
+assert [s for s in names if s.startswith("third_party.a2c_ppo_acktr.model")], sorted(names)[:20]
+print("written")
+"""
+
+_READ_WITH_THE_REFERENCE = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+from ref_import import import_reference
+from helpers import load, assert_close
+ns = import_reference()
+name, path = sys.argv[1], sys.argv[2]
+g = load(name)
+actor_critic, ob_rms = torch.load(path, map_location="cpu", weights_only=False)      # my_pybullet_envs/utils.py:43-46
+assert isinstance(actor_critic, torch.nn.Module) and type(actor_critic) in (ns.Policy, ns.SplitPolicy), type(actor_critic)
+assert "simgan_amd" not in sys.modules
+flat = np.concatenate([v.detach().numpy().reshape(-1) for v in actor_critic.state_dict().values()])
+assert np.array_equal(flat, g["flat"])
+with torch.no_grad():
+    v, a, lp, _ = actor_critic.act(torch.from_numpy(g["obs"]), None, None, deterministic=True)
+assert_close(v.numpy(), g["value"], what="value"); assert_close(a.numpy(), g["action"], what="action"); assert_close(lp.numpy(), g["logp"], what="logp")
+actor_critic.reset_variance(ns.Box(shape=(g["meta"]["A"],)), -1.0) if g["meta"]["kind"] == "mlp" else None
+print("reference loaded it")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the SimGAN checkout (development container only)")
+@pytest.mark.parametrize("name", ["ckpt_policy_mlp", "ckpt_policy_split"])
+def test_torch_save_of_a_shim_policy_is_loadable_by_the_reference_alone(name, tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tests, tools = os.path.join(root, "tests"), os.path.join(root, "tools")
+    out = str(tmp_path / "saved_by_the_main.pt")
+    w = subprocess.run([sys.executable, "-c", _WRITE_THROUGH_THE_ALIAS.format(tests=tests), name, out], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, PYTHONPATH=root), cwd="/tmp")
+    assert w.returncode == 0 and "written" in w.stdout, w.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-c", _READ_WITH_THE_REFERENCE.format(tests=tests, tools=tools), name, out], capture_output=True,
+                       text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"}, cwd="/tmp")
+    assert r.returncode == 0 and "reference loaded it" in r.stdout, r.stderr[-3000:]
+    # ... and this package's own reader takes it back, like any reference checkpoint
+    c = ck.read_reference_checkpoint(out)
+    assert np.array_equal(_flat(c["state_dict"]), load(name)["flat"])
