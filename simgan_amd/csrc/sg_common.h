@@ -190,7 +190,6 @@ struct sg_ppo {
     int64_t last_perm_count = 0;   // entries of d_perms the last update consumed (sg_ppo_last_perms)
     double* d_loss_acc = nullptr;  // [3] running loss sums over the update
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
-    unsigned long long* d_arrive = nullptr;   // k_ppo_reduce_adam: per-block {step tag, sum of squares} words (+ a give-up flag behind them)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
 };
 

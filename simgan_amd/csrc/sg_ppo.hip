@@ -149,8 +149,6 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
     SG_CHECK(hipMalloc((void**)&a->d_state, sizeof(SgOptState)));
     SG_CHECK(hipMalloc((void**)&a->d_loss_acc, sizeof(double) * 8));
     SG_CHECK(hipMalloc((void**)&a->d_part, sizeof(float) * ((tot + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS + 8)));
-    SG_CHECK(hipMalloc((void**)&a->d_arrive, sizeof(unsigned long long) * 264));
-    SG_CHECK(hipMemsetAsync(a->d_arrive, 0, sizeof(unsigned long long) * 264, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_v, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 8, ctx->stream));
@@ -170,7 +168,6 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (a->d_perms) (void)hipFree(a->d_perms);
     if (a->d_loss_acc) (void)hipFree(a->d_loss_acc);
-    if (a->d_arrive) (void)hipFree(a->d_arrive);
     if (a->d_dbg) (void)hipFree(a->d_dbg);
     if (a->steps_graph) (void)hipGraphExecDestroy(a->steps_graph);
     delete a;
@@ -418,11 +415,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
-    // slab sum + norm + clip + Adam in one launch when its blocks are co-resident by construction (<= 256 = the words one
-    // polling wave covers, and never more than the CUs) and no collective sits between the sum and the norm
-    const int nblk_ra = (d.total + 8 + SG_PPO_RA_PARAMS - 1) / SG_PPO_RA_PARAMS;
-    const char* raenv = getenv("SG_PPO_FUSE_RA");
-    const bool fuse_ra = !ctx->use_comm && nblk_ra <= 256 && nblk_ra <= ctx->num_cu && !(raenv && !strcmp(raenv, "0"));
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
 
     // The E*M optimizer steps (+ one row gather per epoch) depend only on buffer addresses, the minibatch geometry
@@ -451,12 +443,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                     }
                     pa.wbuf_floats = fused ? wb_f : wb_b;
                     launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused, gw);
-                }
-                if (fuse_ra) {
-                    SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce_adam, dim3(nblk_ra), dim3(512), 0, a->d_slabs, G, slab_stride, d.total,
-                              a->policy->d_params, a->d_m, a->d_v, st, e * M + k + 1, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B,
-                              a->d_loss_acc, a->d_arrive, reinterpret_cast<int*>(a->d_arrive + 256));
-                    continue;
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
                           d.total, a->d_grad, a->d_part);
@@ -489,7 +475,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (fuse_ra ? 16 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
@@ -507,12 +493,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     if (!out3) return 0;   // the caller reads the losses later (sg_results_publish): the update stays queued, no host wait
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
-    if (fuse_ra) {   // the stream is idle here: did any block of any step give up waiting for its peers?
-        int gave_up = 0;
-        SG_COPY_SYNC(ctx, &gave_up, a->d_arrive + 256, sizeof gave_up, hipMemcpyDeviceToHost);
-        SG_REQUIRE(!gave_up, "sg_ppo_update: k_ppo_reduce_adam timed out waiting for its peer blocks (the device is shared with "
-                   "another stream's kernels?); set SG_PPO_FUSE_RA=0");
-    }
     const double nu = (double)E * M;
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
     return 0;

@@ -513,105 +513,6 @@ __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_sl
     }
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// k_ppo_reduce_adam: slab sum + ||g|| + clip + Adam in ONE launch (single-GPU runs; SG_PPO_FUSE_RA=0 restores the two
-// launches above).  Round 2 measured a fused kernel on k_ppo_reduce's 275-block grid at 7.4 us against 4.0 + 4.0: the
-// 275-to-275 hand-off of the partial sums cost ~3 us.  This one keeps the hand-off SMALL: a block owns 256 parameters
-// (8 waves: waves 0-3 sum the even slabs of their 64 parameters, waves 4-7 the odd ones, 16 loads in flight per lane), so
-// the north-star policy is 70 blocks and the Laikago one 218 -- all co-resident on the 256 CUs by construction (one
-// launch of <= 256 small blocks on an otherwise idle stream), which is what makes the in-kernel wait legal.
-//   1. reduce: g_i = sum over slabs, fixed order                              (the block's own 256 parameters)
-//   2. publish {step tag, sum of squares} as ONE 8-byte agent-scope store per block; wave 0 polls the <= 256 words with
-//      coalesced agent-scope loads until every word carries this step's tag   (the only cross-block datum)
-//   3. every block adds the partials in the same order -> the same norm, clip coefficient, Adam step
-// The tag is Adam's global step number (monotonic over the object's life), so stale words can never match.  The wait is
-// bounded by the wall clock (2 ms); a block that gives up raises a flag the host checks at the next synchronisation.
-#define SG_PPO_RA_PARAMS 256
-__global__ __launch_bounds__(512) void k_ppo_reduce_adam(const float* slabs, int n_slabs, int slab_stride, int total,
-                                                         float* params, float* m, float* v, const SgOptState* st, int k1,
-                                                         float eps, float max_norm, float inv_mb, double* loss_acc,
-                                                         unsigned long long* arrive, int* fail_flag) {
-    __shared__ float red[8][64];
-    __shared__ float s_sq[4];
-    __shared__ float s_coef;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pw = wave & 3, half = wave >> 2;
-    const int i = blockIdx.x * SG_PPO_RA_PARAMS + pw * 64 + lane;
-    const int t = st->t0 + k1;
-    // this lane's parameter and moments are requested before anything else: they arrive under the reduction
-    const bool own = half == 0 && i < total;
-    float p0 = 0.f, m0 = 0.f, v0 = 0.f;
-    if (own) { p0 = params[i]; m0 = m[i]; v0 = v[i]; }
-    const float step_size = st->step_size2[t & 1], bc2_sqrt = st->bc2_sqrt2[t & 1];
-    float g = 0.f;
-    if (i < total + 8) {
-        for (int s0 = half; s0 < n_slabs; s0 += 32) {
-            float x[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int sidx = s0 + 2 * u;
-                x[u] = slabs[(size_t)(sidx < n_slabs ? sidx : s0) * slab_stride + i];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) g += (s0 + 2 * u < n_slabs) ? x[u] : 0.f;
-        }
-    }
-    red[wave][lane] = g;
-    __syncthreads();
-    if (half == 0) {
-        g = red[pw][lane] + red[pw + 4][lane];
-        float sq = (i < total) ? g * g : 0.f;
-        sq = sg_wave_sum(sq);
-        if (lane == 0) s_sq[pw] = sq;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        if (lane == 0) {
-            const float sq = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
-            __hip_atomic_store(arrive + blockIdx.x, ((unsigned long long)(unsigned)t << 32) | (unsigned long long)__float_as_uint(sq),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const int nb = gridDim.x;   // <= 256: at most 4 words per lane
-        unsigned long long w[4];
-        const long long t_start = wall_clock64();
-        bool all = false, gave_up = false;
-        while (!all) {
-            bool mine = true;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int b = lane + 64 * q;
-                w[q] = b < nb ? __hip_atomic_load(arrive + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)(unsigned)t << 32);
-                mine = mine && (unsigned)(w[q] >> 32) == (unsigned)t;
-            }
-            all = __all(mine);
-            if (!all && wall_clock64() - t_start > 200000) { gave_up = true; break; }   // 2 ms at 100 MHz
-        }
-        if (gave_up && lane == 0) *fail_flag = 1;
-        // the same fixed-order sum on every block: lane partials in q order, then the wave tree
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s += (lane + 64 * q < nb) ? __uint_as_float((unsigned)w[q]) : 0.f;
-        s = sg_wave_sum(s);
-        if (lane == 0) {
-            const float norm = sqrtf(s);
-            const float coef = max_norm / (norm + 1e-6f);
-            s_coef = coef > 1.f ? 1.f : coef;
-        }
-    }
-    __syncthreads();
-    if (own) {
-        const float gc = g * s_coef;
-        m0 = m0 + (gc - m0) * (float)(1.0 - 0.9);
-        v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * gc * gc;
-        const float denom = sqrtf(v0) / bc2_sqrt + eps;
-        params[i] = p0 - step_size * (m0 / denom);
-        m[i] = m0;
-        v[i] = v0;
-    }
-    // loss sums sit in elements total .. total+2 of the reduced vector (value_loss.item() etc. are float32, summed in doubles)
-    if (half == 0 && i >= total && i < total + 3) loss_acc[i - total] += (double)(g * inv_mb);
-    if (blockIdx.x == 0 && tid == 448) sg_opt_prepare(const_cast<SgOptState*>(st), t + 1);
-}
-
 // Adam scalars of the update's first step (every later step's are prepared by the preceding k_ppo_adam)
 __global__ void k_opt_prepare_first(SgOptState* st) { sg_opt_prepare(st, st->t0 + 1); }
 
