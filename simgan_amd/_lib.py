@@ -116,6 +116,7 @@ TEST_PROTOTYPES = {
     "sg_test_flag_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p, c_float_p]),
     "sg_test_fetch_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_ll_p]),
     "sg_test_pmc_calibrate": (C.c_int, [H, C.c_int64]),
+    "sg_test_pstep_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p, c_int_p]),
     "sg_test_graph_state": (C.c_int, [H, H, c_int_p]),
     "sg_test_disc_phase_times": (C.c_int, [H, C.c_int, c_ll_p, C.c_int]),
     "sg_test_ppo_phase_times": (C.c_int, [H, C.c_int, c_ll_p, C.c_int]),

@@ -5,6 +5,7 @@
 // share the process's HIP runtime.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <vector>
 
@@ -384,6 +385,8 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int wor
     (void)hipFree(d_data); (void)hipFree(d_sums); (void)hipFree(d_cnt); (void)hipFree(d_st);
     return 0;
 }
+
+#include "sg_test_pstep.hpp"
 
 // Test hook: how the last update of each object was issued -- 0 direct launches, 1 replayed graph, 2 a capture was
 // refused once and the object fell back to direct launches (tests/test_gpu_comm.py).

@@ -15,6 +15,7 @@ SG_API int sg_test_gemm_bench(sg_ctx *ctx, int mode, int MT, int K, int Np, int 
 SG_API int sg_test_mfma_probe(sg_ctx *ctx, int abid, const float *a, const float *b, float *d);
 SG_API int sg_test_flag_probe(sg_ctx *ctx, int mode, int np, int nc, int words, long long *stamps, float *sums);
 SG_API int sg_test_fetch_probe(sg_ctx *ctx, int n_blocks, int waves, int mode, long long *out);
+SG_API int sg_test_pstep_probe(sg_ctx *ctx, int mode, int S, int NW, int cyc_phase, int cyc_w, long long *stamps, int *err4);
 SG_API int sg_test_pmc_calibrate(sg_ctx *ctx, int64_t mbytes);
 /* out[0] / out[1]: how the last PPO update / discriminator epoch was issued: 0 direct, 1 replayed graph, 2 capture refused */
 SG_API int sg_test_graph_state(sg_ppo *a, sg_disc *d, int out[2]);
