@@ -69,12 +69,12 @@ static bool disc_chain_thin(const sg_ctx* ctx, const SgDiscDesc& dd) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     return (kf == 6 && kh == 7) || (kf == 2 && kh == 7) || (kf == 1 && kh == 1);
 }
-static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, const DiscArgs& a) {
+static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, const DiscArgs& a, const PregatherArgs& next) {
     const int kf = dd.Fp / 16, kh = dd.Hp / 16;
     const dim3 block(64 * (kf > kh ? kf : kh));   // one wave per 16 output columns: no idle wave to launch and drain
 #define SG_CHAIN4(KF_, KH_)                                                                                         \
     SG_LAUNCH(ctx, SG_PROF_DISC_CHAIN, (k_disc_chain4<KF_, KH_>), grid, block, 0, a.params, a.wT, a.ops, a.part, a.dbg, \
-              a.B, a.G, a.inv_B, a.lambda_)
+              a.B, a.G, a.inv_B, a.lambda_, next)
     if (kf == 6 && kh == 7) SG_CHAIN4(6, 7);
     else if (kf == 2 && kh == 7) SG_CHAIN4(2, 7);
     else SG_CHAIN4(1, 1);
@@ -505,6 +505,10 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     }
 
     const int G = (B_loc + 15) / 16;
+    // k_disc_wgrad takes {G, flags, step index} packed into one preloaded scalar (sg_wgrad_pack)
+    SG_REQUIRE(G < 1024 && n_d < (1 << SG_WGRAD_PACK_K1_BITS) && dd.Hp < 65536 && dd.Fp < 32768,
+               "sg_disc_update_gail_dyn: %d steps per epoch / batch %d exceed the weight-gradient kernel's packed arguments "
+               "(< %d steps, batch < 16384 per rank)", n_d, B_loc, 1 << SG_WGRAD_PACK_K1_BITS);
     // scratch of one step: operand stacks | per-workgroup vector partials | (data-parallel) flat gradient
     const bool thin = disc_chain_thin(ctx, dd);
     const bool gw = disc_needs_gw(ctx, dd);
@@ -542,7 +546,10 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int th_ = dd.Hp / 16, tf_ = dd.Fp / 16;
     const char* xenv = getenv("SG_WGRAD_XCD");
     wa.xcd_map = (th_ <= 7 && n_vec <= (8 - th_) * (th_ + tf_) && !(xenv && !strcmp(xenv, "0"))) ? 1 : 0;
-    const int n_wgrad_blocks = wa.xcd_map ? 8 * (th_ + tf_) + 2 * G : n_tiles + n_vec + 2 * G;
+    // blocks that copy the next step's rows: 2G beside the 4-row chain blocks (they have the time), else 2G in k_disc_wgrad,
+    // which then only keeps one spare block when no tile slot is free for the lane that evaluates the next Adam scalars
+    const int n_gather_wgrad = !thin ? 2 * G : (wa.xcd_map && (8 - th_) * (th_ + tf_) > n_vec) ? 0 : 1;
+    const int n_wgrad_blocks = (wa.xcd_map ? 8 * (th_ + tf_) : n_tiles + n_vec) + n_gather_wgrad;
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
     // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit
@@ -587,10 +594,11 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             pg.alpha = d->d_alpha + al_next;
             pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
             wa.next = pg;
-            if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg), a);
+            if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg + 2 * G), a, pg);
             else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a, gw);
             SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa.ops, wa.params, wa.m,
-                      wa.v, wa.st, wa.G, dd.Hp, dd.Fp, (wa.xcd_map ? 1 : 0) | (wa.grad_out ? 2 : 0) | (wa.dbg ? 4 : 0), wa);
+                      wa.v, wa.st, wa.wT, dd.Hp | (dd.Fp << 16),
+                      sg_wgrad_pack(wa.G, (wa.xcd_map ? 1 : 0) | (wa.grad_out ? 2 : 0) | (wa.dbg ? 4 : 0) | (thin ? 8 : 0), wa.k1), wa);
             if (sharded) {
                 SG_TRY(sg_comm_allreduce_f32(ctx, grad, (int64_t)grad_f));
                 hipLaunchKernelGGL(k_disc_adam_flat, dim3(nblk), dim3(256), 0, ctx->stream, d->d_params, d->d_m, d->d_v, grad,

@@ -446,7 +446,16 @@ struct Chain4Args {
 };
 template <int KF, int KH>
 __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const float* wT, float* ops, float* part_base,
-                                                    long long* dbg, int B, int G, float inv_B, float lambda_) {
+                                                    long long* dbg, int B, int G, float inv_B, float lambda_, PregatherArgs next) {
+    // Workgroups past the 12G chain blocks copy the NEXT step's rows into the other parity's operand stacks (nothing of this
+    // step touches those).  Such a block is one cold kernarg fetch + one round trip to the epoch's row copies in HBM + the
+    // write-back of its stores, ~2.5 us: riding in k_disc_wgrad (rounds 1-3) it was that kernel's longest block (round 4:
+    // the weight-gradient kernel with ONLY these blocks left in it cost the step 2.46 us, the whole kernel 2.9); beside the
+    // 4.3 us chain blocks it is free.  `next` is the only argument that is not preloaded, and only these blocks read it.
+    if ((int)blockIdx.x >= 12 * G) {
+        if (next.ops) sg_disc_pregather(next, (int)blockIdx.x - 12 * G);
+        return;
+    }
     const Chain4Args a{params, wT, ops, part_base, dbg, B, G, inv_B, lambda_};
     constexpr int Fp = 16 * KF, Hp = 16 * KH, ldF = Fp + 4, ldH = Hp + 4;
     constexpr int ldAF = Fp + 8, ldAH = Hp + 8;   // LDS activation strides: rows 0..3 land in disjoint bank octets
@@ -743,66 +752,76 @@ __device__ __forceinline__ void sg_adam_apply(float* p, float* m, float* v, floa
 
 #define SG_WGRAD_THREADS 512
 
-// The first 16 dwords of the argument list are what a weight-tile block needs to form its operand addresses (and its
-// parameter / moment addresses): the code object asks the command processor to preload them into SGPRs
-// (-amdgpu-kernarg-preload-count), so the operand loads -- the block's critical path -- do not first wait for a kernarg
-// fetch from memory after a fresh launch.  Everything else rides in the struct behind them and is read when it is needed.
+// The first 16 dwords of the argument list are ALL a weight-tile block and a vector block ever read before their last
+// stores: the code object asks the command processor to preload them into SGPRs (-amdgpu-kernarg-preload-count), while
+// anything that rides in the struct behind them is a scalar load from the kernarg segment -- a cold miss after every
+// launch, ~0.7 us, and scalar loads return out of order, so the FIRST use of any of them waits for all of them.  Round 4
+// measured exactly that at the head of every tile block (wall-clock stamps: first operand load issued 0.8 us after the
+// block's first instruction; blockDim.x alone -- a hidden argument -- was enough to cause it).  Fourteen dwords are
+// preloaded for this signature (the user-SGPR budget): six pointers, the two padded extents in one dword, and {G, flags, the
+// step's index} in another; the per-workgroup partials sit at a fixed place behind the two operand stacks, so their address
+// follows from c_ops and the step's parity.  The struct serves the short blocks that copy the next step's rows, the
+// data-parallel gradient output and the loss scalars of one lane.
+#define SG_WGRAD_PACK_K1_BITS 18
+__host__ __device__ __forceinline__ int sg_wgrad_pack(int G, int flags, int k1) { return G | (flags << 10) | (k1 << 14); }
+constexpr float SG_DISC_ADAM_EPS = 1e-8f;   // a2c/algo/gail.py:48 (torch.optim.Adam default)
 __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_ops, float* c_params, float* c_m, float* c_v,
-                                                                const SgOptState* c_st, int c_G, int c_Hp, int c_Fp,
-                                                                int c_flags /* 1: xcd_map, 2: grad_out set, 4: dbg set */,
+                                                                const SgOptState* c_st, float* c_wT, int c_HpFp /* Hp | Fp << 16 */,
+                                                                int c_pack /* G | flags << 10 | k1 << 14; flags 1: xcd_map, 2: grad_out set, 4: dbg set, 8: 4-row chain */,
                                                                 WgradArgs a) {
     __shared__ float red[8][256];
     SgDiscDesc d;   // same arithmetic as sg_make_disc_desc, from the preloaded extents
     d.F = 0; d.Hd = 0;
-    d.Hp = c_Hp; d.Fp = c_Fp; d.ldF = c_Fp + 4; d.ldH = c_Hp + 4;
+    d.Hp = c_HpFp & 0xffff; d.Fp = (int)((unsigned)c_HpFp >> 16); d.ldF = d.Fp + 4; d.ldH = d.Hp + 4;
     d.w1 = 0; d.b1 = d.Hp * d.ldF; d.w2 = d.b1 + d.Hp; d.b2 = d.w2 + d.Hp * d.ldH;
     d.w3 = d.b2 + d.Hp; d.b3 = d.w3 + d.Hp; d.total = d.b3 + 16;
-    a.ops = c_ops; a.params = c_params; a.m = c_m; a.v = c_v; a.st = c_st; a.G = c_G; a.xcd_map = c_flags & 1;
-    const bool has_grad_out = c_flags & 2, has_dbg = c_flags & 4;
+    const int c_G = c_pack & 1023, c_flags = (c_pack >> 10) & 15, c_k1 = (int)((unsigned)c_pack >> 14);
+    const bool xcd_map = c_flags & 1, has_grad_out = c_flags & 2, has_dbg = c_flags & 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
-    const int nw = blockDim.x >> 6;
+    constexpr int nw = SG_WGRAD_THREADS / 64;   // not blockDim.x: a hidden argument is a kernarg fetch too
     const int th = d.Hp >> 4, tf = d.Fp >> 4;
     const int T2 = th * th, T1 = th * tf;
-    const int Kt = 64 * a.G;
+    const int Kt = 64 * c_G;
     // test hook: wall clock (100 MHz) at block start / after the operand loads / after the LDS reduce / end
     long long* stamp = (has_dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
     if (stamp) stamp[0] = wall_clock64();
-    int b;
-    if (a.xcd_map) {
+    // Role of this workgroup: 0 weight tile b, 1 vector block b, 2 everything short (copy the next step's rows and / or
+    // evaluate the next step's Adam scalars, or nothing).  The tile and vector bodies come FIRST in the kernel's code and the
+    // double-precision pow() of the Adam scalars is instantiated once, behind them: the instruction cache is cold after
+    // every launch and the tile blocks are the kernel's critical path.
+    int role, b = 0, j = 0;
+    bool prepare = false, gather = false;
+    if (xcd_map) {
         // Workgroups go to the 8 XCDs round-robin by index and every XCD has its own L2.  All tiles of one row
         // panel (same 16 rows of W2 / W1, hence the same left slab) are given to one XCD, so an XCD pulls one
         // left slab plus the right slabs from the memory side instead of nearly all of both stacks; the spare XCD
         // column(s) take the vector blocks and, in the first slot left over, the lane that evaluates the next
-        // step's Adam scalars.  The 2G blocks that copy the next step's rows come last: they are short.
+        // step's Adam scalars.  Behind the 16-row chain kernel, the 2G blocks that copy the next step's rows come last.
         const int ntv = 8 * (th + tf), NV = (3 * d.Hp + 4 + 63) / 64;
         const bool has_spare = (8 - th) * (th + tf) > NV;
-        if ((int)blockIdx.x >= ntv) {
-            const int j = blockIdx.x - ntv;
-            if (!has_spare && j == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
-            if (a.next.ops) sg_disc_pregather(a.next, j);
-            return;
-        }
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        if (xcd < th) b = slot < th ? xcd * th + slot : T2 + xcd * tf + (slot - th);
+        if ((int)blockIdx.x >= ntv) { role = 2; j = blockIdx.x - ntv; prepare = !has_spare && j == 0; gather = !(c_flags & 8); }
+        else if (xcd < th) { role = 0; b = slot < th ? xcd * th + slot : T2 + xcd * tf + (slot - th); }
         else {
             const int vid = (xcd - th) * (th + tf) + slot;
-            if (vid == NV && tid == 0) {
-                sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
-                if (stamp) stamp[3] = wall_clock64();
-            }
-            if (vid >= NV) return;
-            b = T2 + T1 + vid;
+            if (vid < NV) { role = 1; b = T2 + T1 + vid; }
+            else { role = 2; prepare = vid == NV; }
         }
     } else {
         // linear order: the 2G blocks that prepare the next step first (one lane also evaluates its Adam scalars)
-        if ((int)blockIdx.x < 2 * a.G) {
-            if (blockIdx.x == 0 && tid == 0) sg_opt_prepare(a.next.st, a.st->t0 + a.k1 + 1);
-            if (a.next.ops) sg_disc_pregather(a.next, blockIdx.x);
-            return;
-        }
-        b = blockIdx.x - 2 * a.G;
+        const int ng = (c_flags & 8) ? 1 : 2 * c_G;   // the 4-row chain kernel copies the next step's rows itself
+        if ((int)blockIdx.x < ng) { role = 2; j = blockIdx.x; prepare = j == 0; gather = !(c_flags & 8); }
+        else { b = blockIdx.x - ng; role = b < T2 + T1 ? 0 : 1; }
     }
-    if (b < T2 + T1) {
+    if (__builtin_expect(role == 2, 0)) {
+        if (prepare && tid == 0) {
+            sg_opt_prepare(const_cast<SgOptState*>(c_st), c_st->t0 + c_k1 + 1);
+            if (stamp) stamp[3] = wall_clock64();
+        }
+        if (gather && a.next.ops) sg_disc_pregather(a.next, j);
+        return;
+    }
+    if (role == 0) {
         const bool w2 = b < T2;
         const int t = w2 ? b : b - T2;
         const int tm = w2 ? t / th : t / tf, tn = w2 ? t % th : t % tf;
@@ -813,11 +832,11 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
         float4 sc = float4{0.f, 0.f, 1.f, 1.f};   // both slots of the Adam scalars; the step's parity picks one at the end
         int t0 = 0;
         if (tid < 256 && !has_grad_out) {
-            p0 = a.params[idx]; m0 = a.m[idx]; v0 = a.v[idx];
-            sc = *reinterpret_cast<const float4*>(a.st->step_size2);
-            t0 = a.st->t0;
+            p0 = c_params[idx]; m0 = c_m[idx]; v0 = c_v[idx];
+            sc = *reinterpret_cast<const float4*>(c_st->step_size2);
+            t0 = c_st->t0;
         }
-        const SgStacks stk = sg_disc_stacks(const_cast<float*>(a.ops), Kt, d.Hp, d.Fp, d.ldF);
+        const SgStacks stk = sg_disc_stacks(const_cast<float*>(c_ops), Kt, d.Hp, d.Fp, d.ldF);
         // the two [Kt x 16] slabs this tile contracts: contiguous in the tiled stacks
         const float* L = (w2 ? stk.L2 : stk.L1) + (size_t)tm * Kt * 16;
         const float* Rr = (w2 ? stk.R2 : stk.R1t) + (size_t)tn * Kt * 16;
@@ -865,19 +884,19 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
 #pragma unroll
                 for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) g += r8[w];
             }
-            if (a.grad_out) a.grad_out[idx] = g;
+            if (has_grad_out) a.grad_out[idx] = g;
             else {
-                const bool odd = (t0 + a.k1) & 1;
+                const bool odd = (t0 + c_k1) & 1;
                 const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
                 m0 = m0 + (g - m0) * (float)(1.0 - 0.9);
                 v0 = v0 * (float)0.999 + (float)(1.0 - 0.999) * g * g;
-                const float denom = sqrtf(v0) / bc2_sqrt + a.eps;
+                const float denom = sqrtf(v0) / bc2_sqrt + SG_DISC_ADAM_EPS;
                 p0 = p0 - step_size * (m0 / denom);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_nontemporal_store(p0, a.params + idx);
-                __builtin_nontemporal_store(m0, a.m + idx);
-                __builtin_nontemporal_store(v0, a.v + idx);
-                if (a.wT) { __builtin_nontemporal_store(p0, a.wT + img0); __builtin_nontemporal_store(p0, a.wT + img1); }
+                __builtin_nontemporal_store(p0, c_params + idx);
+                __builtin_nontemporal_store(m0, c_m + idx);
+                __builtin_nontemporal_store(v0, c_v + idx);
+                if (c_wT) { __builtin_nontemporal_store(p0, c_wT + img0); __builtin_nontemporal_store(p0, c_wT + img1); }
             }
         }
         if (stamp) stamp[3] = wall_clock64();
@@ -885,16 +904,18 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
         // vectors: db1 | db2 | dw3 | db3 and the three loss sums from the per-workgroup partials.  Vector block vb
         // owns elements [64 vb, 64 vb + 64); its 8 waves each sum an eighth of the partials (independent
         // loads, 4 in flight per lane), then combine through LDS.
-        const int Hp = d.Hp, nparts = a.nparts, stride = 4 * Hp, NE = 3 * Hp + 4;
+        const int Hp = d.Hp, nparts = ((c_flags & 8) ? 12 : 2) * c_G, stride = 4 * Hp, NE = 3 * Hp + 4;
+        // scratch = stacks[0] | stacks[1] | partials (disc_update_core); this step's stacks are stacks[(k1 - 1) & 1]
+        const float* c_part = c_ops + (size_t)(2 - ((c_k1 - 1) & 1)) * ((size_t)Kt * (3 * d.Hp + d.ldF + d.Fp));
         const int i = 64 * (b - (T2 + T1)) + lane;
-        const float4 sc = *reinterpret_cast<const float4*>(a.st->step_size2);
-        const bool odd = (a.st->t0 + a.k1) & 1;
+        const float4 sc = *reinterpret_cast<const float4*>(c_st->step_size2);
+        const bool odd = (c_st->t0 + c_k1) & 1;
         const float step_size = odd ? sc.y : sc.x, bc2_sqrt = odd ? sc.w : sc.z;
         // the element's parameter and moments are requested with the partials: one memory round trip per block
         const bool is_param = wave == 0 && i < 3 * Hp + 1 && !has_grad_out;
         const int pidx = i < Hp ? d.b1 + i : i < 2 * Hp ? d.b2 + (i - Hp) : i < 3 * Hp ? d.w3 + (i - 2 * Hp) : d.b3;
         float pv = 0.f, pm = 0.f, pvv = 0.f;
-        if (is_param) { pv = a.params[pidx]; pm = a.m[pidx]; pvv = a.v[pidx]; }
+        if (is_param) { pv = c_params[pidx]; pm = c_m[pidx]; pvv = c_v[pidx]; }
         float g = 0.f;
         if (i < NE) {
             for (int s0 = wave; s0 < nparts; s0 += 16 * nw) {   // 16 loads in flight per lane: one round trip at batch 128
@@ -902,7 +923,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int sidx = s0 + u * nw;
-                    t[u] = sidx < nparts ? a.part[(size_t)sidx * stride + i] : 0.f;
+                    t[u] = sidx < nparts ? c_part[(size_t)sidx * stride + i] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) g += t[u];
@@ -920,21 +941,21 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
                 for (int w = 0; w < SG_WGRAD_THREADS / 64; ++w) g += r8[w];
             }
             if (i < 3 * Hp + 1) {
-                if (a.grad_out) a.grad_out[pidx] = g;
+                if (has_grad_out) a.grad_out[pidx] = g;
                 else {
                     pm = pm + (g - pm) * (float)(1.0 - 0.9);
                     pvv = pvv * (float)0.999 + (float)(1.0 - 0.999) * g * g;
-                    const float denom = sqrtf(pvv) / bc2_sqrt + a.eps;
-                    a.params[pidx] = pv - step_size * (pm / denom);
-                    a.m[pidx] = pm;
-                    a.v[pidx] = pvv;
+                    const float denom = sqrtf(pvv) / bc2_sqrt + SG_DISC_ADAM_EPS;
+                    c_params[pidx] = pv - step_size * (pm / denom);
+                    c_m[pidx] = pm;
+                    c_v[pidx] = pvv;
                 }
             }
             // loss_expert, loss_policy, loss_gp sums sit in elements 3Hp+1..3 = lanes l0+1..l0+3 of the last block
             const int l0 = (3 * Hp) & 63;
             const float el_s = __shfl(g, l0 + 1), pl_s = __shfl(g, l0 + 2), gp_s = __shfl(g, l0 + 3);
             if (i == 3 * Hp) {
-                if (a.grad_out) {
+                if (has_grad_out) {
                     a.grad_out[d.total + 0] = el_s; a.grad_out[d.total + 1] = pl_s; a.grad_out[d.total + 2] = gp_s;
                 } else {
                     // a2c/algo/gail.py:181-184: loss.item() etc. are float32, accumulated in Python doubles
