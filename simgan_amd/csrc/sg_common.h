@@ -90,7 +90,7 @@ void sg_disc_unpad(const SgDiscDesc& d, const float* padded, float* flat);
 
 // ------------------------------------------------------------------------------------ handles
 enum { SG_PROF_DISC_CHAIN = 0, SG_PROF_DISC_WGRAD, SG_PROF_PPO_FWD, SG_PROF_PPO_BWD,
-       SG_PROF_PPO_REDUCE, SG_PROF_RELABEL, SG_PROF_PPO_ADAM, SG_PROF_COUNT };
+       SG_PROF_PPO_REDUCE, SG_PROF_RELABEL, SG_PROF_PPO_ADAM, SG_PROF_DISC_STEP, SG_PROF_COUNT };
 
 struct SgProfSlot {
     double total_ms = 0.0;
@@ -225,6 +225,7 @@ struct sg_disc {
     int returns_n = 0;
     bool returns_none = true;
     uint64_t rng_calls = 0;
+    long long* d_dbg_step4 = nullptr;   // k_disc_step4's stamps (SG_STEP4_STAMPS builds, tools/step4_times.py)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
 };
 

@@ -40,6 +40,7 @@
 int sg_fill_perm(sg_ctx* ctx, int64_t* d_perm, int64_t n, uint64_t seed, uint64_t stream_id);
 
 #include "sg_disc_kernels.hpp"
+#include "sg_disc_step4.hpp"
 
 // shape-specialised instances: north-star / Laikago (F 86, Hd 100), Hopper (F 25, Hd 100), the
 // tiny test shape, and the run-time-shape fallback
@@ -79,6 +80,19 @@ static void launch_disc_chain4(sg_ctx* ctx, const SgDiscDesc& dd, dim3 grid, con
     else if (kf == 2 && kh == 7) SG_CHAIN4(2, 7);
     else SG_CHAIN4(1, 1);
 #undef SG_CHAIN4
+}
+// One launch per step (sg_disc_step4.hpp) for the shapes the 4-row kernel exists for.
+static void launch_disc_step4(sg_ctx* ctx, const SgDiscDesc& dd, sg_disc* d, float* ops, int B, int G, int k1, const Step4Args& sa) {
+    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
+    const dim3 grid(((12 * G + 7) & ~7) + 8 * (kh + kf) + 2 * G), block(512);
+    SgOptState* st = reinterpret_cast<SgOptState*>(d->d_state);
+#define SG_STEP4(KF_, KH_)                                                                                                   \
+    SG_LAUNCH(ctx, SG_PROF_DISC_STEP, (k_disc_step4<KF_, KH_>), grid, block, 0, d->d_params, d->d_m, d->d_v, d->d_wT, ops, st, \
+              sg_wgrad_pack(G, 0, k1), B, sa)
+    if (kf == 6 && kh == 7) SG_STEP4(6, 7);
+    else if (kf == 2 && kh == 7) SG_STEP4(2, 7);
+    else SG_STEP4(1, 1);
+#undef SG_STEP4
 }
 static void disc_refresh_images(sg_disc* d) {
     hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
@@ -259,7 +273,9 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipMalloc((void**)&d->d_params, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_m, sizeof(float) * tot));
     SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&d->d_state, sizeof(SgOptState)));
+    static_assert(sizeof(SgOptState) <= 4 * SG_STEP4_FLAG_WORD0, "the hand-off flags of k_disc_step4 sit behind the optimizer state");
+    SG_CHECK(hipMalloc((void**)&d->d_state, SG_STEP4_STATE_BYTES));   // SgOptState | hand-off flags | error word (k_disc_step4)
+    SG_CHECK(hipMemsetAsync(d->d_state, 0, SG_STEP4_STATE_BYTES, ctx->stream));
     SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
     SG_CHECK(hipMalloc((void**)&d->d_scal, sizeof(double) * 8));
     {
@@ -347,6 +363,9 @@ extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int6
     d->opt_t = step;
     const int t0 = (int)step;
     SG_COPY_SYNC(d->ctx, &reinterpret_cast<SgOptState*>(d->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice);
+    // the hand-off flags of k_disc_step4 hold Adam step numbers: a step count set from outside may repeat old ones
+    SG_CHECK(hipMemsetAsync(reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_FLAG_WORD0, 0, 4 * SG_STEP4_MAX_FLAGS * SG_STEP4_FLAG_STRIDE, d->ctx->stream));
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
     return 0;
 }
 
@@ -550,6 +569,10 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     // which then only keeps one spare block when no tile slot is free for the lane that evaluates the next Adam scalars
     const int n_gather_wgrad = !thin ? 2 * G : (wa.xcd_map && (8 - th_) * (th_ + tf_) > n_vec) ? 0 : 1;
     const int n_wgrad_blocks = (wa.xcd_map ? 8 * (th_ + tf_) : n_tiles + n_vec) + n_gather_wgrad;
+    // one launch per step (k_disc_step4) whenever the 4-row kernel runs a full, unsharded batch; SG_DISC_FUSED=0: two launches
+    const char* fenv = getenv("SG_DISC_FUSED");
+    const bool fused = thin && !sharded && !owned && !d->d_dbg && wa.xcd_map && 12 * G <= SG_STEP4_MAX_FLAGS &&
+                       !(fenv && !strcmp(fenv, "0"));
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
     // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit
@@ -594,6 +617,12 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             pg.alpha = d->d_alpha + al_next;
             pg.ops = (k + 1 < n_d) ? stacks[(k + 1) & 1] : nullptr;
             wa.next = pg;
+            if (fused) {
+                Step4Args sa;
+                sa.next = pg; sa.loss_acc = d->d_loss_acc; sa.dbg = d->d_dbg_step4;
+                launch_disc_step4(ctx, dd, d, a.ops, a.B, G, wa.k1, sa);
+                continue;
+            }
             if (thin) launch_disc_chain4(ctx, dd, dim3(n_chain_wg + 2 * G), a, pg);
             else launch_disc_chain(ctx, dd, dim3(n_chain_wg), lds, a, gw);
             SG_LAUNCH(ctx, SG_PROF_DISC_WGRAD, k_disc_wgrad, dim3(n_wgrad_blocks), dim3(SG_WGRAD_THREADS), 0, wa.ops, wa.params, wa.m,
@@ -618,7 +647,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
                                   (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size,
-                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
+                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | (fused ? 8u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }

@@ -444,23 +444,21 @@ struct Chain4Args {
     int B, G;
     float inv_B, lambda_;
 };
-template <int KF, int KH>
-__global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const float* wT, float* ops, float* part_base,
-                                                    long long* dbg, int B, int G, float inv_B, float lambda_, PregatherArgs next) {
-    // Workgroups past the 12G chain blocks copy the NEXT step's rows into the other parity's operand stacks (nothing of this
-    // step touches those).  Such a block is one cold kernarg fetch + one round trip to the epoch's row copies in HBM + the
-    // write-back of its stores, ~2.5 us: riding in k_disc_wgrad (rounds 1-3) it was that kernel's longest block (round 4:
-    // the weight-gradient kernel with ONLY these blocks left in it cost the step 2.46 us, the whole kernel 2.9); beside the
-    // 4.3 us chain blocks it is free.  `next` is the only argument that is not preloaded, and only these blocks read it.
-    if ((int)blockIdx.x >= 12 * G) {
-        if (next.ops) sg_disc_pregather(next, (int)blockIdx.x - 12 * G);
-        return;
-    }
-    const Chain4Args a{params, wT, ops, part_base, dbg, B, G, inv_B, lambda_};
+// A store another workgroup reads.  WT = false: a plain store (the reader is the NEXT launch; the end-of-kernel release
+// writes the line back).  WT = true: a write-through (agent-scope, `sc1`) store for a reader inside the SAME launch
+// (k_disc_step4: the weight-gradient workgroups poll a flag and read with L1-bypassing loads).
+template <bool WT>
+__device__ __forceinline__ void sg_pub(float* p, float v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// The serial part of one discriminator step on 4-row blocks (see k_disc_chain4 below); sm = 5*4*ldAH + 4*ldAF + 64 floats of LDS.
+template <int KF, int KH, bool WT>
+__device__ __forceinline__ void sg_chain4_body(const Chain4Args& a, float* sm) {
     constexpr int Fp = 16 * KF, Hp = 16 * KH, ldF = Fp + 4, ldH = Hp + 4;
     constexpr int ldAF = Fp + 8, ldAH = Hp + 8;   // LDS activation strides: rows 0..3 land in disjoint bank octets
     constexpr int o_b1 = Hp * ldF, o_b2 = o_b1 + Hp + Hp * ldH, o_w3 = o_b2 + Hp, o_b3 = o_w3 + Hp;
-    __shared__ __attribute__((aligned(16))) float sm[5 * 4 * ldAH + 4 * ldAF + 64];
     const float* P = a.params;
     const float* I_W1 = a.wT;                    // images (sg_thin.hpp): W1 for x W1^T, W2 for h W2^T,
     const float* I_W2 = I_W1 + Hp * Fp;          // W2^T for d W2, W1^T for d W1
@@ -517,7 +515,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             sg4_mma<Fp, 1>(ax, w1, lane, o);
             h1 = sg_tanh(o[0] + b1c);
             H1[s * ldAH + col] = h1;
-            R2s[SG_STK(Kt, r0 + s, col)] = h1;
+            sg_pub<WT>(&R2s[SG_STK(Kt, r0 + s, col)], h1);
         }
         SG_PHASE_SYNC(1);
         if (actH) {
@@ -546,13 +544,13 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             if (actH) {
                 const float dz = grad * w3c * (1.f - h2 * h2);
                 DZ2[s * ldAH + col] = dz;
-                L2s[SG_STK(Kt, r0 + s, col)] = dz;
+                sg_pub<WT>(&L2s[SG_STK(Kt, r0 + s, col)], dz);
                 const float gw = sg4_colsum(grad * h2), gb = sg4_colsum(dz);
-                if (s == 0) { part[2 * Hp + col] = gw; part[Hp + col] = gb; }
+                if (s == 0) { sg_pub<WT>(&part[2 * Hp + col], gw); sg_pub<WT>(&part[Hp + col], gb); }
             }
             if (wave == 0) {
                 const float db3 = sg4_colsum(grad), ls = sg4_colsum(loss);
-                if (lane < 4) part[3 * Hp + lane] = lane == 0 ? db3 : (lane == 1 && !is_policy) || (lane == 2 && is_policy) ? ls : 0.f;
+                if (lane < 4) sg_pub<WT>(&part[3 * Hp + lane], lane == 0 ? db3 : (lane == 1 && !is_policy) || (lane == 2 && is_policy) ? ls : 0.f);
             }
         }
         SG_PHASE_SYNC(3);
@@ -562,9 +560,9 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             sg4_load_a<Hp, 1>(ad, DZ2, ldAH, lane);
             sg4_mma<Hp, 1>(ad, w2t, lane, o);
             const float dz1 = o[0] * (1.f - h1 * h1);
-            L1s[SG_STK(Kt, r0 + s, col)] = dz1;
+            sg_pub<WT>(&L1s[SG_STK(Kt, r0 + s, col)], dz1);
             const float sb = sg4_colsum(dz1);
-            if (s == 0) part[col] = sb;
+            if (s == 0) sg_pub<WT>(&part[col], sb);
         }
     } else {
         // ------------------------------------------------ mixup group: gradient penalty on 4 rows
@@ -595,7 +593,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             __builtin_amdgcn_sched_barrier(0);
             h1 = sg_tanh(o[0] + b1c);
             H1[s * ldAH + col] = h1;
-            R2s[SG_STK(Kt, rowB + s, col)] = h1;
+            sg_pub<WT>(&R2s[SG_STK(Kt, rowB + s, col)], h1);
         }
         SG_PHASE_SYNC(8);
         if (actH) {
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             h2 = sg_tanh(o[0] + b2c);
             const float d2 = w3c * (1.f - h2 * h2);
             D2[s * ldAH + col] = d2;
-            L2s[SG_STK(Kt, rowA + s, col)] = d2;
+            sg_pub<WT>(&L2s[SG_STK(Kt, rowA + s, col)], d2);
         }
         SG_PHASE_SYNC(9);
         if (actH) {   // u1 = d2 W2
@@ -620,7 +618,7 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             u1 = o[0];
             const float d1 = u1 * (1.f - h1 * h1);
             D1[s * ldAH + col] = d1;
-            L1s[SG_STK(Kt, rowA + s, col)] = d1;
+            sg_pub<WT>(&L1s[SG_STK(Kt, rowA + s, col)], d1);
         }
         SG_PHASE_SYNC(10);
         if (actF) {   // g = d1 W1
@@ -649,16 +647,16 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             const float nn = __builtin_amdgcn_sqrtf(ss);                      // v_sqrt_f32 / v_rcp_f32 (1 ulp): the correctly rounded
             const bool valid = bi0 + s < a.B;                                 // sequences are ~60 VALU instructions on this phase's path
             const float cr = (valid && nn > 0.f) ? a.lambda_ * 2.f * a.inv_B * (nn - 1.f) * __builtin_amdgcn_rcpf(nn) : 0.f;
-            if (actF) R1t[SG_STK(Kt, rowA + s, col)] = gown * cr;                // gb
+            if (actF) sg_pub<WT>(&R1t[SG_STK(Kt, rowA + s, col)], gown * cr);                // gb
             if (wave == 0) {
                 const float rl = sg4_colsum(valid ? (nn - 1.f) * (nn - 1.f) : 0.f);
-                if (lane < 4) part[3 * Hp + lane] = lane == 3 ? rl : 0.f;         // sum (|g|-1)^2
+                if (lane < 4) sg_pub<WT>(&part[3 * Hp + lane], lane == 3 ? rl : 0.f);         // sum (|g|-1)^2
             }
             if (actH) {
                 const float bd1 = o[0] * cr;
                 const float bu1 = bd1 * (1.f - h1 * h1);
                 BU1[s * ldAH + col] = bu1;
-                R2s[SG_STK(Kt, rowA + s, col)] = bu1;
+                sg_pub<WT>(&R2s[SG_STK(Kt, rowA + s, col)], bu1);
                 sb1 = bd1 * u1;
             }
         }
@@ -672,9 +670,9 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             const float t3 = bd2 * s2;                                   // -> dw3
             const float z2b = (-2.f * h2 * (bd2 * w3c)) * s2;
             Z2B[s * ldAH + col] = z2b;
-            L2s[SG_STK(Kt, rowB + s, col)] = z2b;
+            sg_pub<WT>(&L2s[SG_STK(Kt, rowB + s, col)], z2b);
             const float sw = sg4_colsum(t3), sb = sg4_colsum(z2b);
-            if (s == 0) { part[2 * Hp + col] = sw; part[Hp + col] = sb; }
+            if (s == 0) { sg_pub<WT>(&part[2 * Hp + col], sw); sg_pub<WT>(&part[Hp + col], sb); }
         }
         SG_PHASE_SYNC(14);
         if (actH) {   // h1b = z2b W2
@@ -683,13 +681,31 @@ __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const 
             sg4_load_a<Hp, 1>(av, Z2B, ldAH, lane);
             sg4_mma<Hp, 1>(av, w2t, lane, o);
             const float z1b = (o[0] - 2.f * h1 * sb1) * (1.f - h1 * h1);
-            L1s[SG_STK(Kt, rowB + s, col)] = z1b;
+            sg_pub<WT>(&L1s[SG_STK(Kt, rowB + s, col)], z1b);
             const float sb = sg4_colsum(z1b);
-            if (s == 0) part[col] = sb;
+            if (s == 0) sg_pub<WT>(&part[col], sb);
         }
     }
     SG_PHASE_SYNC(31);
     if (a.dbg && tid == 0) a.dbg[blockIdx.x * 32 + 29] = wall_clock64();
+}
+#define SG_CHAIN4_LDS_FLOATS(KF, KH) (5 * 4 * (16 * (KH) + 8) + 4 * (16 * (KF) + 8) + 64)
+
+template <int KF, int KH>
+__global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const float* wT, float* ops, float* part_base,
+                                                    long long* dbg, int B, int G, float inv_B, float lambda_, PregatherArgs next) {
+    // Workgroups past the 12G chain blocks copy the NEXT step's rows into the other parity's operand stacks (nothing of this
+    // step touches those).  Such a block is one cold kernarg fetch + one round trip to the epoch's row copies in HBM + the
+    // write-back of its stores, ~2.5 us: riding in k_disc_wgrad (rounds 1-3) it was that kernel's longest block (round 4:
+    // the weight-gradient kernel with ONLY these blocks left in it cost the step 2.46 us, the whole kernel 2.9); beside the
+    // 4.3 us chain blocks it is free.  `next` is the only argument that is not preloaded, and only these blocks read it.
+    if ((int)blockIdx.x >= 12 * G) {
+        if (next.ops) sg_disc_pregather(next, (int)blockIdx.x - 12 * G);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float sm[SG_CHAIN4_LDS_FLOATS(KF, KH)];
+    const Chain4Args a{params, wT, ops, part_base, dbg, B, G, inv_B, lambda_};
+    sg_chain4_body<KF, KH, false>(a, sm);
 }
 
 // The four weight images of k_disc_chain4 from the padded parameter vector (after sg_disc_set_params).

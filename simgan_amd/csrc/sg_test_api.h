@@ -20,6 +20,7 @@ SG_API int sg_test_pmc_calibrate(sg_ctx *ctx, int64_t mbytes);
 /* out[0] / out[1]: how the last PPO update / discriminator epoch was issued: 0 direct, 1 replayed graph, 2 capture refused */
 SG_API int sg_test_graph_state(sg_ppo *a, sg_disc *d, int out[2]);
 SG_API int sg_test_disc_phase_times(sg_disc *d, int enable, long long *out, int n_blocks);
+SG_API int sg_test_disc_step4_times(sg_disc *d, int enable, long long *out, int n_blocks);
 SG_API int sg_test_ppo_phase_times(sg_ppo *a, int enable, long long *out, int n_blocks);
 /* kind 0: permutation of [0, n) -> int64 out; 1: uniform [0,1) -> float out; 2: standard normal -> float out */
 SG_API int sg_test_rng(sg_ctx *ctx, int kind, int64_t n, uint64_t seed, void *out);

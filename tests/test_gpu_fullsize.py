@@ -256,3 +256,90 @@ def test_disc_epoch_prefix_hopper_shape_vs_oracle(world):
     assert n_d == steps == D.last_n_steps
     assert_close(losses, olosses, what="D losses after 64 steps (Hopper shape)")
     assert_close(D.get_flat_params(), par, what="D params after 64 steps (Hopper shape)")
+
+
+def _disc_epoch(sg, ro, expert, eperm, pperm, alpha, p0, fused, ctx=None, Fin=F):
+    import os
+    old = os.environ.get("SG_DISC_FUSED")
+    os.environ["SG_DISC_FUSED"] = "1" if fused else "0"
+    try:
+        D = sg.algo.gail.Discriminator(Fin, HD, None, seed=11) if ctx is None else sg.algo.gail.Discriminator(Fin, HD, None, ctx=ctx, seed=11)
+        D.set_flat_params(p0)
+        losses = D.update_gail_dyn(Loader(expert, B), ro, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+        return np.asarray(losses, dtype=np.float64), D.get_flat_params(), D.get_adam()
+    finally:
+        if old is None:
+            os.environ.pop("SG_DISC_FUSED", None)
+        else:
+            os.environ["SG_DISC_FUSED"] = old
+
+
+def test_one_launch_step_is_bit_identical_to_the_two_launch_step(world):
+    """k_disc_step4 (chain and weight-gradient workgroups in one launch, joined by a flag hand-off inside it) against
+    k_disc_chain4 + k_disc_wgrad on the same 256 steps: same arithmetic in the same order, so every weight, both Adam
+    moments and the loss sums must be EQUAL -- a single stale word crossing the hand-off would show."""
+    sg, ro = world["sg"], world["ro"]
+    rng = np.random.default_rng(77)
+    steps = 256
+    expert = world["expert"][:steps * B]
+    eperm = rng.permutation(steps * B).astype(np.int64)
+    pperm = rng.permutation(T * N).astype(np.int64)
+    alpha = rng.random(steps * B).astype(np.float32)
+    p0 = sg.algo.gail.Discriminator(F, HD, None, seed=5).get_flat_params()
+    l2, p2, a2 = _disc_epoch(sg, ro, expert, eperm, pperm, alpha, p0, fused=False)
+    l1, p1, a1 = _disc_epoch(sg, ro, expert, eperm, pperm, alpha, p0, fused=True)
+    assert np.array_equal(l1, l2), (l1, l2)
+    assert np.array_equal(p1, p2), f"{(p1 != p2).sum()} of {p1.size} weights differ, worst {np.abs(p1 - p2).max():.3g}"
+    for x, y in zip(a1[:2], a2[:2]):
+        assert np.array_equal(x, y)
+    assert np.abs(p1 - p0).max() > 1e-2
+
+
+def test_one_launch_step_hand_off_under_load(world):
+    """The same comparison while the GPU is shared unevenly: six contexts on threads run the one-launch epoch at the same
+    time (their workgroups interleave on the CUs, flags and data race through a loaded fabric) and each must reproduce the
+    two-launch result of an idle GPU bit for bit.  (A hand-off whose flag can overtake its data passes on an idle chip and
+    fails here: the store drain in front of the flag was first missing, and this is how it showed.)"""
+    import threading
+    sg, _lib, ro = world["sg"], world["_lib"], world["ro"]
+    rng = np.random.default_rng(78)
+    steps = 192
+    expert = world["expert"][:steps * B]
+    eperm = rng.permutation(steps * B).astype(np.int64)
+    pperm = rng.permutation(T * N).astype(np.int64)
+    alpha = rng.random(steps * B).astype(np.float32)
+    p0 = sg.algo.gail.Discriminator(F, HD, None, seed=6).get_flat_params()
+    want_l, want_p, _ = _disc_epoch(sg, ro, expert, eperm, pperm, alpha, p0, fused=False)
+    feat = ro.obs_feat.numpy().copy()
+    import os
+    os.environ["SG_DISC_FUSED"] = "1"
+    n_threads, rounds = 6, 3
+    out, errs = [None] * n_threads, []
+
+    def work(i):
+        try:
+            ctx = _lib.Context(0)
+            r = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F, ctx=ctx)
+            r.obs_feat.copy_(r.obs_feat.new_tensor(feat))
+            res = []
+            for _ in range(rounds):
+                D = sg.algo.gail.Discriminator(F, HD, None, ctx=ctx, seed=11)
+                D.set_flat_params(p0)
+                ls = D.update_gail_dyn(Loader(expert, B), r, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+                res.append((np.asarray(ls, dtype=np.float64), D.get_flat_params()))
+            out[i] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    try:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        [t.start() for t in th]
+        [t.join(600) for t in th]
+    finally:
+        os.environ.pop("SG_DISC_FUSED", None)
+    assert not errs, errs
+    for i, res in enumerate(out):
+        assert res is not None, f"thread {i} did not finish"
+        for ls, p in res:
+            assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
+            assert np.array_equal(ls, want_l)
