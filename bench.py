@@ -108,6 +108,8 @@ def algorithmic_work(w, world, disc_sharded=False):
     kernels = {
         "disc_chain": ("k_disc_chain4", "mfma", d_chain_flops, 2 * B_rank * F * 4),
         "disc_wgrad": ("k_disc_wgrad", "mfma", d_wgrad_flops, 0),
+        # one launch per optimizer step (csrc/sg_disc_step4.hpp): the chain and the weight-gradient workgroups side by side
+        "disc_step": ("k_disc_step4", "mfma", d_step_flops, 2 * B_rank * F * 4),
         "ppo_fwd": ("k_ppo_fwd_critic" if crit_first else "k_ppo_fwd", "mfma", 0 if fused else fwd_flops + crit_bwd_flops,
                     0 if fused else mb * (O + (3 if crit_first else 0)) * 4),
         "ppo_bwd": ("k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused else fwd_flops) - crit_bwd_flops, mb * (O + A + 4) * 4),
@@ -472,16 +474,19 @@ def main():
     learner.update()
     ctx.profile(False)
     prof = {name: ctx.profile_read(i) for i, name in enumerate(
-        ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam"])}
+        ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam", "disc_step"])}
 
     if rank == 0:
         work = algorithmic_work(w, world, ctx.disc_sharded)
         env_steps = w["T"] * w["N"] * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = env_steps * args.steps / elapsed
-        dom = "disc_chain" if w["E_d"] else "ppo_bwd"    # the kernel most of the update's time goes to
-        dom_kernel = ("k_disc_chain4" if w["E_d"] else "k_ppo_bwd")
-        dom_flops = work["d_chain_flops"] if w["E_d"] else work["ppo_step_flops"]
+        # the kernel most of the update's time goes to: the discriminator step -- one launch (k_disc_step4) where the library
+        # runs it so, else its chain kernel -- or, without a discriminator, the PPO backward
+        one_launch = bool(w["E_d"]) and prof["disc_step"][1] > 0
+        dom = ("disc_step" if one_launch else "disc_chain") if w["E_d"] else "ppo_bwd"
+        dom_kernel = ("k_disc_step4" if one_launch else "k_disc_chain4") if w["E_d"] else "k_ppo_bwd"
+        dom_flops = (work["d_step_flops"] if one_launch else work["d_chain_flops"]) if w["E_d"] else work["ppo_step_flops"]
         dg_ms, dg_n = prof[dom]
         dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
         achieved = dom_flops / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0

@@ -677,6 +677,16 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                 std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(),
                 std::chrono::duration<double, std::milli>(t_done - t_enq1).count());
     }
+    if (fused && acc[0] != acc[0]) {   // NaN: either the data, or a weight-gradient workgroup of k_disc_step4 gave up waiting
+        unsigned err = 0;
+        SG_COPY_SYNC(ctx, &err, reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD, sizeof err, hipMemcpyDeviceToHost);
+        if (err) {
+            SG_CHECK(hipMemsetAsync(reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD, 0, sizeof err, ctx->stream));
+            SG_REQUIRE(false, "sg_disc_update_gail_dyn: the weight-gradient workgroups of k_disc_step4 waited %d s for the chain "
+                       "workgroups of their own launch and gave up (the discriminator's state is undefined; SG_DISC_FUSED=0 runs "
+                       "the step as two launches)", (int)(SG_STEP4_TIMEOUT_TICKS / 100000000ll));
+        }
+    }
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / n_d);
     return 0;
 }

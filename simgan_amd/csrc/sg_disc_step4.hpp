@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
         const unsigned want = (unsigned)(t0 + c_k1);
         if (!(SG_ABL & 1) && wave == 7 && !sg_step4_wait(flags, 4 * c_G, n_chain, want, lane) && lane == 0) *sh_ok = 0;
         __syncthreads();
-        if (!*sh_ok) { if (tid == 0) atomicOr(err, 1u); return; }
+        if (!*sh_ok) { if (tid == 0) { atomicOr(err, 1u); a.loss_acc[0] = __builtin_nanf(""); } return; }   // the host sees NaN losses, then the error word
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, alt = acc;
         const int half_chunks = n_chunks >> 1;
         // contract chunks [c_lo, c_hi): this wave's share, two chunks per batch; `between` runs once, after the first batch's
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
         });
         __syncthreads();
         SG_STAMP(ts1);
-        if (!*sh_ok) { if (tid == 0) atomicOr(err, 1u); return; }
+        if (!*sh_ok) { if (tid == 0) { atomicOr(err, 1u); a.loss_acc[0] = __builtin_nanf(""); } return; }   // the host sees NaN losses, then the error word
         contract(half_chunks, n_chunks, []() {});
         acc += alt;
 #pragma unroll
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
         __syncthreads();
         if (!(SG_ABL & 1) && wave == 7 && !sg_step4_wait(flags, 0, n_chain, (unsigned)(t0 + c_k1), lane) && lane == 0) *sh_ok = 0;
         __syncthreads();
-        if (!*sh_ok) { if (tid == 0) atomicOr(err, 1u); return; }
+        if (!*sh_ok) { if (tid == 0) { atomicOr(err, 1u); a.loss_acc[0] = __builtin_nanf(""); } return; }   // the host sees NaN losses, then the error word
         float g = 0.f;
         if (i < NE) {
             for (int s0 = wave; s0 < nparts; s0 += 16 * nw) {
