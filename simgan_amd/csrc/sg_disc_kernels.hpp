@@ -695,10 +695,10 @@ template <int KF, int KH>
 __global__ __launch_bounds__(512) void k_disc_chain4(const float* params, const float* wT, float* ops, float* part_base,
                                                     long long* dbg, int B, int G, float inv_B, float lambda_, PregatherArgs next) {
     // Workgroups past the 12G chain blocks copy the NEXT step's rows into the other parity's operand stacks (nothing of this
-    // step touches those).  Such a block is one cold kernarg fetch + one round trip to the epoch's row copies in HBM + the
-    // write-back of its stores, ~2.5 us: riding in k_disc_wgrad (rounds 1-3) it was that kernel's longest block (round 4:
-    // the weight-gradient kernel with ONLY these blocks left in it cost the step 2.46 us, the whole kernel 2.9); beside the
-    // 4.3 us chain blocks it is free.  `next` is the only argument that is not preloaded, and only these blocks read it.
+    // step touches those).  Such a block is one round trip to the epoch's row copies in HBM + the write-back of its stores,
+    // ~2.5 us: riding in k_disc_wgrad (rounds 1-3) it was as long as that kernel's tile blocks (round 4: the weight-gradient
+    // kernel with ONLY these blocks left in it cost the step 2.46 us, the whole kernel 2.9); beside the 4.3 us chain blocks
+    // it is free.
     if ((int)blockIdx.x >= 12 * G) {
         if (next.ops) sg_disc_pregather(next, (int)blockIdx.x - 12 * G);
         return;
@@ -768,16 +768,16 @@ __device__ __forceinline__ void sg_adam_apply(float* p, float* m, float* v, floa
 
 #define SG_WGRAD_THREADS 512
 
-// The first 16 dwords of the argument list are ALL a weight-tile block and a vector block ever read before their last
-// stores: the code object asks the command processor to preload them into SGPRs (-amdgpu-kernarg-preload-count), while
-// anything that rides in the struct behind them is a scalar load from the kernarg segment -- a cold miss after every
-// launch, ~0.7 us, and scalar loads return out of order, so the FIRST use of any of them waits for all of them.  Round 4
-// measured exactly that at the head of every tile block (wall-clock stamps: first operand load issued 0.8 us after the
-// block's first instruction; blockDim.x alone -- a hidden argument -- was enough to cause it).  Fourteen dwords are
-// preloaded for this signature (the user-SGPR budget): six pointers, the two padded extents in one dword, and {G, flags, the
-// step's index} in another; the per-workgroup partials sit at a fixed place behind the two operand stacks, so their address
-// follows from c_ops and the step's parity.  The struct serves the short blocks that copy the next step's rows, the
-// data-parallel gradient output and the loss scalars of one lane.
+// Everything a weight-tile block and a vector block read before their last stores rides in the preloaded scalars (the
+// code object asks the command processor to preload the leading arguments into SGPRs: fourteen dwords for this signature):
+// six pointers, the two padded extents in one dword, and {G, flags, the step's index} in another; the per-workgroup partials
+// sit at a fixed place behind the two operand stacks, so their address follows from c_ops and the step's parity.  The struct
+// behind them serves the blocks that copy the next step's rows (16-row chain kernel only), the data-parallel gradient output
+// and the loss scalars of one lane.  (Round 4 measured what this buys: nothing -- a kernarg field or the hidden blockDim.x
+// read at the head of every block costs <= 0.04 us per launch, tools/probes/launch_floor.hip; wall-clock stamps that seemed to
+// show 0.8 us between a tile block's first instruction and its first operand load were showing the stamps' own s_memrealtime
+// round trips.  What DID bound this kernel was found by removing block bodies one at a time: the blocks copying the next
+// step's rows were as long as the tile blocks, 2.5 against 2.9 us over an empty launch -- they now ride beside the chain.)
 #define SG_WGRAD_PACK_K1_BITS 18
 __host__ __device__ __forceinline__ int sg_wgrad_pack(int G, int flags, int k1) { return G | (flags << 10) | (k1 << 14); }
 constexpr float SG_DISC_ADAM_EPS = 1e-8f;   // a2c/algo/gail.py:48 (torch.optim.Adam default)
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
     const int c_G = c_pack & 1023, c_flags = (c_pack >> 10) & 15, c_k1 = (int)((unsigned)c_pack >> 14);
     const bool xcd_map = c_flags & 1, has_grad_out = c_flags & 2, has_dbg = c_flags & 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
-    constexpr int nw = SG_WGRAD_THREADS / 64;   // not blockDim.x: a hidden argument is a kernarg fetch too
+    constexpr int nw = SG_WGRAD_THREADS / 64;
     const int th = d.Hp >> 4, tf = d.Fp >> 4;
     const int T2 = th * th, T1 = th * tf;
     const int Kt = 64 * c_G;
@@ -802,9 +802,7 @@ __global__ __launch_bounds__(SG_WGRAD_THREADS) void k_disc_wgrad(const float* c_
     long long* stamp = (has_dbg && threadIdx.x == 0) ? a.dbg + 32 * 256 + 4 * blockIdx.x : nullptr;
     if (stamp) stamp[0] = wall_clock64();
     // Role of this workgroup: 0 weight tile b, 1 vector block b, 2 everything short (copy the next step's rows and / or
-    // evaluate the next step's Adam scalars, or nothing).  The tile and vector bodies come FIRST in the kernel's code and the
-    // double-precision pow() of the Adam scalars is instantiated once, behind them: the instruction cache is cold after
-    // every launch and the tile blocks are the kernel's critical path.
+    // evaluate the next step's Adam scalars, or nothing); the double-precision pow() of the Adam scalars is instantiated once.
     int role, b = 0, j = 0;
     bool prepare = false, gather = false;
     if (xcd_map) {

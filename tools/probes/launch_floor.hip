@@ -10,6 +10,9 @@ struct Big { float* p[30]; int n[20]; };
 __global__ void k_empty() {}
 __global__ void k_args(float* a, float* b, float* c, float* d, float* e, int x, int y, int z, int w) { if (x == -12345) a[0] = 1.f; }
 __global__ void k_big(float* a, int x, Big s) { if (x == -12345) a[0] = (float)s.n[3]; }
+__global__ __launch_bounds__(512) void k_big_use(float* a, int x, Big s) { a[blockIdx.x * 512 + threadIdx.x] = (float)(s.n[3] + x); }
+__global__ __launch_bounds__(512) void k_args_use(float* a, int x, int y) { a[blockIdx.x * 512 + threadIdx.x] = (float)(y + x); }
+__global__ __launch_bounds__(512) void k_bdim_use(float* a, int x, int y) { a[blockIdx.x * blockDim.x + threadIdx.x] = (float)(y + x); }
 __global__ __launch_bounds__(512) void k_lds(float* a, int x) { __shared__ float sm[2048]; if (x == -12345) { sm[threadIdx.x] = 1.f; __syncthreads(); a[0] = sm[(threadIdx.x + 1) & 511]; } }
 __global__ __launch_bounds__(512) void k_store(float* a, int x) { a[blockIdx.x * 512 + threadIdx.x] = (float)x; }
 __global__ __launch_bounds__(512) void k_load(const float* a, float* o, int x) { float v = a[blockIdx.x * 512 + threadIdx.x]; if (v == -12345.f) o[0] = v; }
@@ -50,6 +53,12 @@ int main() {
         run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_args, dim3(grid), dim3(512), 0, st, buf, buf, buf, buf, buf, i, 1, 2, 3); });
         snprintf(nm, sizeof nm, "2 args + 320-byte struct            grid %4d x 512", grid);
         run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_big, dim3(grid), dim3(512), 0, st, buf, i, big); });
+        snprintf(nm, sizeof nm, "store of a struct field (kernarg fetch) grid %4d x 512", grid);
+        run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_big_use, dim3(grid), dim3(512), 0, st, buf, i, big); });
+        snprintf(nm, sizeof nm, "store of a preloadable scalar        grid %4d x 512", grid);
+        run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_args_use, dim3(grid), dim3(512), 0, st, buf, i, 3); });
+        snprintf(nm, sizeof nm, "same, indexed with blockDim.x        grid %4d x 512", grid);
+        run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_bdim_use, dim3(grid), dim3(512), 0, st, buf, i, 3); });
         snprintf(nm, sizeof nm, "8 KB static LDS                     grid %4d x 512", grid);
         run(nm, st, n, [&](int i) { hipLaunchKernelGGL(k_lds, dim3(grid), dim3(512), 0, st, buf, i); });
         snprintf(nm, sizeof nm, "one 4-byte store per thread         grid %4d x 512", grid);
