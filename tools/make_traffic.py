@@ -70,5 +70,5 @@ for wl in ("northstar", "hopper", "laikago", "refine", "hopper_ppo"):
                             "lib_sha256": build.get("lib_sha256"), "kernels": out}
 json.dump(doc, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
 for wl, d in doc["workloads"].items():
-    print(wl, {k: (v.get("hbm_bytes_per_launch"), v.get("rocprof_avg_us")) for k, v in d["kernels"].items() if k.startswith(("k_disc_chain", "k_disc_wgrad", "k_ppo_"))},
+    print(wl, {k: (v.get("hbm_bytes_per_launch"), v.get("rocprof_avg_us")) for k, v in d["kernels"].items() if k.startswith(("k_disc_chain", "k_disc_wgrad", "k_disc_step", "k_ppo_"))},
           (d["lib_sha256"] or "no build record")[:12], d["source"][-60:])
