@@ -105,14 +105,18 @@ def algorithmic_work(w, world, disc_sharded=False):
     crit_first = (not fused) and ((mb + 31) // 32) * 3 > 256
     crit_fwd = O * H + H * H + H
     crit_bwd_flops = mb * 2 * (2 * crit_fwd - O * H) if crit_first else 0
+    # SplitPolicy whose 3 G workgroups are resident together: ONE launch per step, every trunk fused, the actor pairs exchanging
+    # their head outputs inside it (csrc/sg_ppo.hip: pair; k_ppo_pair) -- no forward launch
+    pair = (not fused) and (not crit_first) and ((mb + 31) // 32) * 3 <= 256 and os.environ.get("SG_PPO_PAIR") != "0"
     kernels = {
         "disc_chain": ("k_disc_chain4", "mfma", d_chain_flops, 2 * B_rank * F * 4),
         "disc_wgrad": ("k_disc_wgrad", "mfma", d_wgrad_flops, 0),
         # one launch per optimizer step (csrc/sg_disc_step4.hpp): the chain and the weight-gradient workgroups side by side
         "disc_step": ("k_disc_step4", "mfma", d_step_flops, 2 * B_rank * F * 4),
-        "ppo_fwd": ("k_ppo_fwd_critic" if crit_first else "k_ppo_fwd", "mfma", 0 if fused else fwd_flops + crit_bwd_flops,
-                    0 if fused else mb * (O + (3 if crit_first else 0)) * 4),
-        "ppo_bwd": ("k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused else fwd_flops) - crit_bwd_flops, mb * (O + A + 4) * 4),
+        "ppo_fwd": ("k_ppo_fwd_critic" if crit_first else "k_ppo_fwd", "mfma", 0 if fused or pair else fwd_flops + crit_bwd_flops,
+                    0 if fused or pair else mb * (O + (3 if crit_first else 0)) * 4),
+        "ppo_bwd": ("k_ppo_pair" if pair else "k_ppo_bwd", "mfma", ppo_step_flops - (0 if fused or pair else fwd_flops) - crit_bwd_flops,
+                    mb * (O + A + 4) * 4),
         "ppo_reduce": ("k_ppo_reduce", "hbm", 0, P_pi * 4),          # the gradient vector; the slabs it sums are an implementation artefact
         "ppo_adam": ("k_ppo_adam", "hbm", 0, P_pi * 4 * 7),          # grad + params / m / v read and written
         "relabel_fwd": ("k_disc_forward", "mfma", relabel_flops, TN * (F + 1) * 4 if w["E_d"] else 0),

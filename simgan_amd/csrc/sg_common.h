@@ -191,6 +191,7 @@ struct sg_ppo {
     double* d_loss_acc = nullptr;  // [3] running loss sums over the update
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
+    unsigned* d_pair = nullptr;    // k_ppo_pair: error word
 };
 
 struct sg_disc {

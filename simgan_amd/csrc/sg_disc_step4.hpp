@@ -58,6 +58,17 @@ __device__ __forceinline__ float sg_ld_sc1(__amdgpu_buffer_rsrc_t r, int byte_of
 }
 
 // One wave waits until the flags of workgroups [lo, hi) all hold `want`; false on time-out.
+// Measured and removed, round 4 (north-star, ms per update; 26.19-26.24 with this plain loop):
+//  * FOUR polls kept in flight per waiting wave, issued 0.15 us apart and examined oldest first (asm loads + `s_waitcnt
+//    vmcnt(6)`: the compiler's wait-count pass drains such a pipe every fourth poll): 27.59 -- 91 waiting workgroups x 96 flag
+//    lines x 4 is traffic the chain blocks' write-through stores and the flags themselves queue behind (stores drained 0.3 us
+//    later, flags seen 1.28 us after the last one was raised instead of 0.96);
+//  * ONE sentinel flag per waiting workgroup polled first, the whole set only once it is up: 26.57 (a serial round trip more
+//    at the moment that counts); a further 0.3 us of sleep between the BCE and the mixup flags: 27.6;
+//  * no poll before 3.4 us after the workgroup's start (the chain cannot be done sooner): 26.08-26.20, i.e. the early polls
+//    do not disturb the chain blocks measurably.
+// The hand-off is two fabric round trips -- data acknowledged (0.36-0.40 us), flag visible and sampled (0.96 us) -- and a third
+// for the operands (0.68 us with their transfer); tools/step4_times.py prints them.
 __device__ __forceinline__ bool sg_step4_wait(const unsigned* flags, int lo, int hi, unsigned want, int lane) {
     const long long deadline = wall_clock64() + SG_STEP4_TIMEOUT_TICKS;
     for (int it = 0;; ++it) {

@@ -104,6 +104,15 @@ static void launch_ppo_fwd_critic(sg_ctx* ctx, int MT, const SgPolicyDesc& d, di
     if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<2, 0, 0>), grid, block, lds, pa);
     else SG_LAUNCH(ctx, SG_PROF_PPO_FWD, (k_ppo_fwd_critic<1, 0, 0>), grid, block, lds, pa);
 }
+// SplitPolicy, one launch per step (k_ppo_pair): grid = 3 G workgroups, trunk index fastest
+static void launch_ppo_pair(sg_ctx* ctx, int MT, const SgPolicyDesc& d, int G, size_t lds, const PpoArgs& pa) {
+    const int ko = d.Op / 16, kh = d.Hc == d.H ? d.Hp / 16 : 0;
+    const dim3 block(ppo_block_threads(MT)), grid(3 * G);
+    if (MT == 2 && ko == 1 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_pair<2, 1, 7>), grid, block, lds, pa); return; }   // HopperCombined
+    if (MT == 2 && ko == 4 && kh == 7) { SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_pair<2, 4, 7>), grid, block, lds, pa); return; }   // LaikagoCombined at <= 2720-row minibatches
+    if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_pair<2, 0, 0>), grid, block, lds, pa);
+    else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_pair<1, 0, 0>), grid, block, lds, pa);
+}
 static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid, size_t lds, const PpoArgs& pa, bool fused, bool gw) {
     const int ko = d.Op / 16, kh = d.Hc == d.H ? d.Hp / 16 : 0;
     const dim3 block(ppo_block_threads(MT));
@@ -152,6 +161,8 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
     SG_CHECK(hipMemsetAsync(a->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_v, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 8, ctx->stream));
+    SG_CHECK(hipMalloc((void**)&a->d_pair, SG_PAIR_BYTES));            // k_ppo_pair: error word
+    SG_CHECK(hipMemsetAsync(a->d_pair, 0, SG_PAIR_BYTES, ctx->stream));
     SgOptState st;
     memset(&st, 0, sizeof st);
     st.lr = cfg->lr;
@@ -169,6 +180,7 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     if (a->d_perms) (void)hipFree(a->d_perms);
     if (a->d_loss_acc) (void)hipFree(a->d_loss_acc);
     if (a->d_dbg) (void)hipFree(a->d_dbg);
+    if (a->d_pair) (void)hipFree(a->d_pair);
     if (a->steps_graph) (void)hipGraphExecDestroy(a->steps_graph);
     delete a;
     return 0;
@@ -224,6 +236,9 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     SG_COPY_SYNC(a->ctx, a->d_m, pm.data(), sizeof(float) * d.total, hipMemcpyHostToDevice);
     SG_COPY_SYNC(a->ctx, a->d_v, pv.data(), sizeof(float) * d.total, hipMemcpyHostToDevice);
     SG_COPY_SYNC(a->ctx, &reinterpret_cast<SgOptState*>(a->d_state)->t0, &t0, sizeof t0, hipMemcpyHostToDevice);
+    // the words k_ppo_pair's actor workgroups swap carry Adam step numbers: a step count set from outside may repeat old ones,
+    // so the row stacks they live in are cleared before the next update
+    a->scratch_key = 0;
     a->opt_t = step;
     return 0;
 }
@@ -398,6 +413,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     pa.use_clipped = a->cfg.use_clipped_value_loss;
     pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
     pa.st = reinterpret_cast<SgOptState*>(a->d_state); pa.G = G; pa.k1 = 0;
+    pa.pair = a->d_pair;
     for (int t = 0; t < 3; ++t) {
         const bool on = t < d.n_trunks;
         pa.H1[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
@@ -412,6 +428,12 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const char* cfenv = getenv("SG_PPO_CRITIC_FIRST");
     const bool crit_first = !gw && !fused && d.kind == SG_POLICY_SPLIT && MT <= 2 && lds_fc <= (size_t)ctx->lds_bytes &&
                             (cfenv ? cfenv[0] == '1' : G * d.n_trunks > ctx->num_cu);
+    // SplitPolicy whose 3 G (row group, trunk) workgroups are all resident at once: ONE launch per step, every trunk fused,
+    // the two actor workgroups of a row group exchanging their head outputs inside it (k_ppo_pair).  SG_PPO_PAIR=0: two launches.
+    const char* penv = getenv("SG_PPO_PAIR");
+    const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
+                      lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP <= d.ldH && !a->d_dbg &&
+                      !(penv && !strcmp(penv, "0"));
     const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
@@ -431,7 +453,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                 pa.mb = step_cnt[(size_t)e * M + k];
                 pa.X = epX + rb * d.ldO; pa.ACT = epACT + rb * d.A; pa.SC = epSC + rb;
                 pa.k1 = e * M + k + 1;
-                if (crit_first) {
+                if (pair) {
+                    pa.wbuf_floats = wb_f;
+                    launch_ppo_pair(ctx, MT, d, G, lds_fc, pa);
+                } else if (crit_first) {
                     pa.wbuf_floats = wb_f;
                     launch_ppo_fwd_critic(ctx, MT, d, dim3(G, d.n_trunks), lds_fc > lds_f ? lds_fc : lds_f, pa);
                     pa.wbuf_floats = wb_b;
@@ -475,7 +500,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
@@ -493,6 +518,16 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     if (!out3) return 0;   // the caller reads the losses later (sg_results_publish): the update stays queued, no host wait
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
+    if (pair && (acc[0] != acc[0] || acc[1] != acc[1] || acc[2] != acc[2])) {   // NaN: either the data, or an actor workgroup of k_ppo_pair gave up waiting
+        unsigned err = 0;
+        SG_COPY_SYNC(ctx, &err, a->d_pair + SG_PAIR_ERR_WORD, sizeof err, hipMemcpyDeviceToHost);
+        if (err) {
+            SG_CHECK(hipMemsetAsync(a->d_pair + SG_PAIR_ERR_WORD, 0, sizeof err, ctx->stream));
+            SG_REQUIRE(false, "sg_ppo_update: an actor workgroup of k_ppo_pair waited %d s for its partner's head outputs and gave "
+                       "up (the policy's state is undefined; SG_PPO_PAIR=0 runs the step as two launches)",
+                       (int)(SG_PAIR_TIMEOUT_TICKS / 100000000ll));
+        }
+    }
     const double nu = (double)E * M;
     for (int i = 0; i < 3; ++i) out3[i] = (float)(acc[i] / nu);
     return 0;

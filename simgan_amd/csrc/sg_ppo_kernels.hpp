@@ -45,7 +45,15 @@ struct PpoArgs {
     long long* dbg;       // optional phase timestamps [block][16] (test hook), NULL in production
     SgOptState* st;       // optimizer scalars (read by k_ppo_adam; prepared one step ahead by the previous k_ppo_adam)
     int k1, G;            // 1-based step index within the update; row groups
+    unsigned* pair;       // k_ppo_pair: the error word an actor workgroup raises when its partner never shows up
 };
+
+// k_ppo_pair (SplitPolicy, one launch per step): the two actor workgroups of a row group exchange their head outputs
+#define SG_PAIR_ERR_WORD 0
+#define SG_PAIR_BYTES 64
+#define SG_PAIR_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
+
+
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): in the backward phases that is
 // the acknowledgement of the gradient-slab stores the phase has just issued -- a memory round trip per phase for data no
@@ -170,7 +178,14 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
 // (sg_layer_*_u), the bias gradients come from column sums of the finished dZ tiles, and two waves per SIMD hide each
 // other's LDS / barrier latencies -- what two co-resident 16-row workgroups per CU did, with the weights staged once and
 // one slab per 32 rows.
-template <int MT, int KO, int KH, bool FUSED, bool GW = false>
+// PAIR (SplitPolicy, FUSED, every (row group, trunk) workgroup resident at once -- k_ppo_pair): a row's log-prob sums over the
+// heads of BOTH actor trunks (a2c/model_split.py:201-238), which is why rounds 1-3 ran the forward as a launch of its own.  Here
+// the two actor workgroups of a row group swap their [R x Pp] head outputs inside the launch, as write-through {value, step tag}
+// words the partner polls (see the swap below).  The values are those the forward launch used to leave in the OUT
+// stacks and the loss code below is unchanged: results are bit-identical to the two-launch step.  Both workgroups wait for each
+// other, so they must be resident together: they are neighbours in dispatch order (trunk index fastest) and the launch is only
+// used when all its workgroups fit the chip at once; the spin is bounded by the wall clock all the same.
+template <int MT, int KO, int KH, bool FUSED, bool GW = false, bool PAIR = false>
 __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (No spare workgroup for Adam's bias corrections any more: with G x trunks = 256 row-group blocks, two extra blocks
@@ -205,6 +220,9 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
 
     SG_PPO_STAMP(8);
     SG_PPO_WALL(6);
+    unsigned pair_tag = 0;
+    bool pair_failed = false;
+    if (PAIR && !critic) pair_tag = (unsigned)(a.st->t0 + a.k1);
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
     if (!GW) sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
@@ -266,9 +284,39 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         sg_layer_nt_u<MT, GW>(H1, ldH, W + tr.w2, ldH, Hp, Hp, [&](int r, int c, float v) { H2[r * ldH + c] = sg_tanh(v + b2[c]); });
         __syncthreads();
         SG_PPO_STAMP(3);
-        sg_layer_nt_u<MT, GW>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { O0[r * ldP + c] = v + bh[c]; });
+        float* Oown = (PAIR && t == 1) ? O1 : O0;
+        sg_layer_nt_u<MT, GW>(H2, ldH, W + tr.wh, ldH, Hp, tr.Pp, [&](int r, int c, float v) { Oown[r * ldP + c] = v + bh[c]; });
         __syncthreads();
         SG_PPO_STAMP(4);
+        if (PAIR && !critic) {
+            // The swap, low-latency form: every head output travels as an 8-byte {value, step tag} word (one aligned 8-byte
+            // write-through store: the pair arrives together or not at all), and the partner polls the words it needs until they
+            // carry this step's tag -- no store drain, no separate flag, no second round trip for the data behind a flag.  The
+            // words live in the H1 row stacks, which the fused body does not use (2 Pp <= ldH: checked by the launch).
+            float* Ooth = t == 1 ? O0 : O1;
+            unsigned long long* xown = reinterpret_cast<unsigned long long*>(a.H1[t] + (size_t)row0 * ldH);
+            const unsigned long long* xoth = reinterpret_cast<const unsigned long long*>(a.H1[1 - t] + (size_t)row0 * ldH);
+            const int Pown = tr.Pp, Poth = d.trunk[1 - t].Pp;
+            for (int i = tid; i < R * Pown; i += blockDim.x) {
+                const int r = i / Pown, c = i - r * Pown;
+                const unsigned long long w = ((unsigned long long)pair_tag << 32) | (unsigned long long)__float_as_uint(Oown[r * ldP + c]);
+                __hip_atomic_store(xown + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool ok = true;
+            const long long deadline = wall_clock64() + SG_PAIR_TIMEOUT_TICKS;
+            for (int i = tid; i < R * Poth; i += blockDim.x) {
+                const int r = i / Poth, c = i - r * Poth;
+                unsigned long long w = 0;
+                for (int it = 0;; ++it) {
+                    w = __hip_atomic_load(xoth + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) == pair_tag) break;
+                    if ((it & 31) == 31 && wall_clock64() > deadline) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                Ooth[r * ldP + c] = __uint_as_float((unsigned)w);
+            }
+            pair_failed = __syncthreads_or(!ok) != 0;
+        }
     }
     SG_PPO_STAMP(9);
 
@@ -461,11 +509,24 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     }
     SG_PPO_STAMP(15);
     SG_PPO_WALL(7);
+    if (PAIR && pair_failed && tid == 0) {   // the partner never published: the host sees NaN losses, then the error word
+        atomicOr(a.pair + SG_PAIR_ERR_WORD, 1u);
+        slab[d.total + 1] = __builtin_nanf("");
+    }
 }
 
 template <int MT, int KO, int KH, bool FUSED = false, bool GW = false>
 __global__ __launch_bounds__(512) void k_ppo_bwd(PpoArgs a) {
     sg_ppo_bwd_body<MT, KO, KH, FUSED, GW>(a, blockIdx.y, blockIdx.x);
+}
+
+// SplitPolicy, ONE launch per step when its 3 G workgroups fit the chip together: every trunk's fused forward + loss + backward,
+// the two actors of a row group joined by the hand-off described at sg_ppo_bwd_body.  Workgroup 3 g + y is trunk y of row group
+// g (y = 2: the critic), so partners are dispatched back to back.
+template <int MT, int KO, int KH>
+__global__ __launch_bounds__(512) void k_ppo_pair(PpoArgs a) {
+    const int bx = (int)blockIdx.x / 3, t = (int)blockIdx.x - 3 * bx;
+    sg_ppo_bwd_body<MT, KO, KH, true, false, true>(a, t, bx);
 }
 
 // SplitPolicy at minibatches whose (row groups x 3 trunks) exceed the CU count: the critic trunk needs no actor output (its

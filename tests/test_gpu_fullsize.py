@@ -343,3 +343,105 @@ def test_one_launch_step_hand_off_under_load(world):
         for ls, p in res:
             assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
             assert np.array_equal(ls, want_l)
+
+
+# ------------------------------------------------------------------ SplitPolicy: one launch per PPO step (k_ppo_pair)
+PAIR_CASES = [
+    # configs[1] as shipped: 64 row groups of 32 rows x 3 trunks = 192 workgroups, the shape-specialised instance
+    dict(id="hopper-split", O=14, A=7, H=100, f=1, N=256, M=16, E=2),
+    # LaikagoCombined trunks at a 2048-row minibatch (256 envs): the (2, 4, 7) instance
+    dict(id="laikago-split-n256", O=64, A=28, H=100, f=4, N=256, M=16, E=1),
+    # a width no instance is specialised for, ragged last row group: the run-time-shape instance
+    dict(id="split-h72-f2-ragged", O=21, A=14, H=72, f=2, N=37, M=4, E=2),
+]
+
+
+def _ppo_update_split(sg, lib, _lib, c, p0, perms, pair, ctx=None, ro=None):
+    import os
+    old = os.environ.get("SG_PPO_PAIR")
+    os.environ["SG_PPO_PAIR"] = "1" if pair else "0"
+    try:
+        kw = {} if ctx is None else {"ctx": ctx}
+        pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31, **kw)
+        pol.set_flat_params(p0)
+        agent = sg.algo.PPO(pol, 0.2, c["E"], c["M"], 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+        losses = agent.update(ro, perms=perms)
+        return np.asarray(losses, dtype=np.float64), pol.get_flat_params(), agent.get_adam()
+    finally:
+        if old is None:
+            os.environ.pop("SG_PPO_PAIR", None)
+        else:
+            os.environ["SG_PPO_PAIR"] = old
+
+
+def _pair_problem(world, c, seed):
+    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
+    rng = np.random.default_rng(seed)
+    pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31)
+    ro = _filled_rollout(sg, lib, _lib, pol, T, c["N"], c["O"], c["A"], 4, 5)
+    p0 = (pol.get_flat_params() + 0.01 * rng.standard_normal(pol.num_params)).astype(np.float32)
+    perms = np.stack([rng.permutation(T * c["N"]) for _ in range(c["E"])]).astype(np.int64)
+    return ro, p0, perms
+
+
+@pytest.mark.parametrize("c", PAIR_CASES, ids=[c["id"] for c in PAIR_CASES])
+def test_one_launch_split_ppo_step_is_bit_identical_to_the_two_launch_step(world, c):
+    """k_ppo_pair (every trunk's fused forward + backward in one launch, the two actor workgroups of a row group swapping
+    their head outputs through a flag hand-off) against k_ppo_fwd + k_ppo_bwd on the same steps: the swapped values are the ones
+    the forward launch leaves in the OUT stacks and the loss code is shared, so losses, weights and both Adam moments must be
+    EQUAL -- one stale word crossing the hand-off would show."""
+    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
+    ro, p0, perms = _pair_problem(world, c, 91)
+    l2, p2, a2 = _ppo_update_split(sg, lib, _lib, c, p0, perms, pair=False, ro=ro)
+    l1, p1, a1 = _ppo_update_split(sg, lib, _lib, c, p0, perms, pair=True, ro=ro)
+    assert np.array_equal(l1, l2), (l1, l2)
+    assert np.array_equal(p1, p2), f"{(p1 != p2).sum()} of {p1.size} weights differ, worst {np.abs(p1 - p2).max():.3g}"
+    for x, y in zip(a1[:2], a2[:2]):
+        assert np.array_equal(x, y)
+    assert np.abs(p1 - p0).max() > 1e-3
+
+
+def test_one_launch_split_ppo_step_under_load(world):
+    """The same comparison with six contexts on threads running the one-launch update at the same time: the pairs'
+    workgroups interleave with other contexts' on the CUs, and every context must reproduce the two-launch result of an idle
+    GPU bit for bit (no deadlock of a pair whose halves are dispatched apart, no flag overtaking its data)."""
+    import os
+    import threading
+    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
+    c = PAIR_CASES[0]
+    ro, p0, perms = _pair_problem(world, c, 92)
+    want_l, want_p, _ = _ppo_update_split(sg, lib, _lib, c, p0, perms, pair=False, ro=ro)
+    fields = {k: getattr(ro, k).numpy().copy() for k in ("obs", "actions", "value_preds", "returns", "action_log_probs", "masks")}
+    os.environ["SG_PPO_PAIR"] = "1"
+    n_threads, rounds = 6, 3
+    out, errs = [None] * n_threads, []
+
+    def work(i):
+        try:
+            ctx = _lib.Context(0)
+            r = sg.RolloutStorage(T, c["N"], (c["O"],), Box((c["A"],)), 1, 4, ctx=ctx)
+            for k, v in fields.items():
+                getattr(r, k).copy_(getattr(r, k).new_tensor(v))
+            res = []
+            for _ in range(rounds):
+                pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31, ctx=ctx)
+                pol.set_flat_params(p0)
+                agent = sg.algo.PPO(pol, 0.2, c["E"], c["M"], 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+                ls = agent.update(r, perms=perms)
+                res.append((np.asarray(ls, dtype=np.float64), pol.get_flat_params()))
+            out[i] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    try:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        [t.start() for t in th]
+        [t.join(600) for t in th]
+    finally:
+        os.environ.pop("SG_PPO_PAIR", None)
+    assert not errs, errs
+    for i, res in enumerate(out):
+        assert res is not None, f"thread {i} did not finish"
+        for ls, p in res:
+            assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
+            assert np.array_equal(ls, want_l)
