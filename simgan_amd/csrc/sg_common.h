@@ -192,6 +192,7 @@ struct sg_ppo {
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
     unsigned* d_pair = nullptr;    // k_ppo_pair: error word
+    bool pair_primed = false;      // the row stacks were cleared for k_ppo_pair's tagged words and no other mode has run since
 };
 
 struct sg_disc {

@@ -239,6 +239,7 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     // the words k_ppo_pair's actor workgroups swap carry Adam step numbers: a step count set from outside may repeat old ones,
     // so the row stacks they live in are cleared before the next update
     a->scratch_key = 0;
+    a->pair_primed = false;
     a->opt_t = step;
     return 0;
 }
@@ -434,6 +435,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
                       lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP <= d.ldH && !a->d_dbg &&
                       !(penv && !strcmp(penv, "0"));
+    // the words the actor pairs swap live in the H1 row stacks: an update that ran the two-launch step left activations there,
+    // and a bit pattern must never be mistaken for a tagged word -- clear them whenever the mode is (re-)entered
+    if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
+    a->pair_primed = pair;
     const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;

@@ -445,3 +445,31 @@ def test_one_launch_split_ppo_step_under_load(world):
         for ls, p in res:
             assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
             assert np.array_equal(ls, want_l)
+
+
+def test_one_launch_split_ppo_step_after_two_launch_updates_of_the_same_agent(world):
+    """The actor pairs' tagged words live in the H1 row stacks, where the two-launch step keeps activations: an agent that
+    changes mode between updates (SG_PPO_PAIR toggled) must still reproduce the all-two-launch trajectory bit for bit."""
+    import os
+    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
+    c = PAIR_CASES[0]
+    ro, p0, perms = _pair_problem(world, c, 96)
+
+    def run(modes):
+        pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31)
+        pol.set_flat_params(p0)
+        agent = sg.algo.PPO(pol, 0.2, c["E"], c["M"], 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+        out = []
+        for m in modes:
+            os.environ["SG_PPO_PAIR"] = m
+            try:
+                out.append((np.asarray(agent.update(ro, perms=perms), dtype=np.float64), pol.get_flat_params()))
+            finally:
+                os.environ.pop("SG_PPO_PAIR", None)
+        return out
+
+    want = run(["0", "0", "0", "0"])
+    got = run(["0", "1", "0", "1"])
+    for (wl, wp), (gl, gp) in zip(want, got):
+        assert np.array_equal(gl, wl), (gl, wl)
+        assert np.array_equal(gp, wp), f"{(gp != wp).sum()} weights differ"
