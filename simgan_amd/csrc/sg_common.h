@@ -168,6 +168,9 @@ struct sg_rollout {
     int field_slots[SG_F_COUNT] = {0};   // T or T+1
     int field_width[SG_F_COUNT] = {0};
     int64_t* d_perm = nullptr;           // [T*N] scratch permutation
+    // bumped by every entry point that writes obs_feat on the device (upload, upload_step, after_update, fill_synthetic): lets
+    // the discriminator's replicated data-parallel mode see that the rows it all-gathered for the previous epoch are still current
+    uint64_t feat_version = 1;
 };
 
 struct sg_ppo {
@@ -211,6 +214,10 @@ struct sg_disc {
     int64_t last_draws[3] = {0, 0, 0};   // entries of d_eperm / d_pperm / d_alpha the last epoch consumed
     float* d_feat_all = nullptr;   // replicated data-parallel mode: all ranks' next_obs_feat rows
     int64_t feat_all_cap = 0;
+    const float* gather_src = nullptr;   // what d_feat_all currently holds: rows pointer, row count and version of the rollout
+    int64_t gather_rows = 0;             // it was gathered from (0 = nothing reusable)
+    uint64_t gather_version = 0;
+    int64_t n_gathers = 0;               // all-gathers issued so far (test hook)
     int64_t opt_t = 0;             // completed Adam steps (mirrors SgOptState::t0 on the device)
     hipGraphExec_t epoch_graph = nullptr;   // one epoch of update steps, captured once and replayed
     bool graph_refused = false;             // a capture with collectives failed once: stay on direct launches

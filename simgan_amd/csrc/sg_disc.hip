@@ -410,7 +410,7 @@ static int check_index_array(const char* who, const char* name, const int64_t* a
 // sharded mode, one local permutation per rank (each rank contributes batch/world rows to every step).
 static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc, int n_cols, int batch_size,
                             const int64_t* expert_perm, int64_t n_expert_perm, const int64_t* policy_perm, int64_t n_policy_perm,
-                            const float* alpha, int64_t n_alpha, uint64_t seed, float out3[3], int* n_steps) {
+                            const float* alpha, int64_t n_alpha, uint64_t seed, float out3[3], int* n_steps, uint64_t src_version = 0) {
     sg_ctx* ctx = d->ctx;
     const SgDiscDesc& dd = d->desc;
     const int rowF = dd.F;
@@ -455,8 +455,21 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                           (long long)n_alpha, (long long)n_d * batch_size);
     const float* next_feat = rows_local;
     if (replicated) {
-        SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * rowF, ctx->stream));
-        SG_TRY(sg_comm_allgather_f32(ctx, next_feat, d->d_feat_all, TN_loc * rowF));
+        // The gail_epoch calls of one learner update read the SAME rollout (a2c/main_gail_dyn_ppo.py:253-256): the union gathered
+        // for the first of them is reused by the others -- one all-gather (22 MB per rank at the north-star shape) per update
+        // instead of five.  "Same" = the same device rows at the same obs_feat version of the rollout (every entry point that
+        // writes obs_feat bumps it); every rank runs the same call sequence, so every rank decides alike.  Rows the caller
+        // assembled (sg_disc_update_rows) carry no version and are gathered every time.  SG_DISC_GATHER_CACHE=0: always gather.
+        const char* cenv = getenv("SG_DISC_GATHER_CACHE");
+        const bool reuse = src_version && d->gather_version == src_version && d->gather_src == rows_local && d->gather_rows == TN_loc &&
+                           d->feat_all_cap >= TN * rowF && !(cenv && !strcmp(cenv, "0"));
+        if (!reuse) {
+            d->gather_rows = 0;
+            SG_TRY(ensure_cap(&d->d_feat_all, &d->feat_all_cap, TN * rowF, ctx->stream));
+            SG_TRY(sg_comm_allgather_f32(ctx, next_feat, d->d_feat_all, TN_loc * rowF));
+            d->gather_src = rows_local; d->gather_rows = TN_loc; d->gather_version = src_version;
+        }
+        d->n_gathers += reuse ? 0 : 1;
         next_feat = d->d_feat_all;
     }
 
@@ -697,8 +710,9 @@ extern "C" int sg_disc_update_gail_dyn(sg_disc* d, sg_rollout* r, int batch_size
     SG_REQUIRE(d && r, "sg_disc_update_gail_dyn: NULL argument");
     SG_REQUIRE(r->F == d->desc.F, "sg_disc_update_gail_dyn: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
     // policy rows = next_obs_feat = obs_feat[1:]   (a2c/storage.py:172, a2c/algo/gail.py:165)
+    // (the trailing argument: the rollout's obs_feat version, see the replicated mode's all-gather in disc_update_core)
     return disc_update_core(d, r->d_field[SG_F_OBS_FEAT] + (size_t)r->N * r->F, (int64_t)r->T * r->N, r->N, batch_size,
-                            expert_perm, n_expert_perm, policy_perm, n_policy_perm, alpha, n_alpha, seed, out3, n_steps);
+                            expert_perm, n_expert_perm, policy_perm, n_policy_perm, alpha, n_alpha, seed, out3, n_steps, r->feat_version);
 }
 
 extern "C" int sg_disc_update_rows(sg_disc* d, const float* policy_rows, int64_t n_rows, int n_cols, int batch_size,

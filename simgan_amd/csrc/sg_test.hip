@@ -568,6 +568,12 @@ extern "C" int sg_test_disc_step4_times(sg_disc* d, int enable, long long* out, 
     return 0;
 }
 
+extern "C" int sg_test_disc_gathers(sg_disc* d, long long* out) {
+    SG_REQUIRE(d && out, "sg_test_disc_gathers: NULL argument");
+    *out = (long long)d->n_gathers;
+    return 0;
+}
+
 extern "C" int sg_test_ppo_phase_times(sg_ppo* a, int enable, long long* out, int n_blocks) {
     SG_REQUIRE(a, "sg_test_ppo_phase_times: NULL argument");
     SG_CHECK(hipStreamSynchronize(a->ctx->stream));

@@ -22,6 +22,8 @@ SG_API int sg_test_graph_state(sg_ppo *a, sg_disc *d, int out[2]);
 SG_API int sg_test_disc_phase_times(sg_disc *d, int enable, long long *out, int n_blocks);
 SG_API int sg_test_disc_step4_times(sg_disc *d, int enable, long long *out, int n_blocks);
 SG_API int sg_test_ppo_phase_times(sg_ppo *a, int enable, long long *out, int n_blocks);
+/* all-gathers the discriminator's replicated data-parallel mode has issued so far (it reuses the union across the epochs of an update) */
+SG_API int sg_test_disc_gathers(sg_disc *d, long long *out);
 /* kind 0: permutation of [0, n) -> int64 out; 1: uniform [0,1) -> float out; 2: standard normal -> float out */
 SG_API int sg_test_rng(sg_ctx *ctx, int kind, int64_t n, uint64_t seed, void *out);
 #ifdef __cplusplus

@@ -216,6 +216,51 @@ def test_disc_update_global_perms_equal_world1_oracle(world, name, mode):
     assert_close(res[0]["adam"][0], dadam.m, rtol=1e-3, atol=1e-6, what="D Adam m")
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_replicated_disc_reuses_the_gathered_rows_until_the_rollout_changes(world):
+    """Replicated mode gathers every rank's policy rows once per LEARNER UPDATE, not once per epoch: the gail_epoch calls of an
+    update read the same device-resident rollout.  Three epochs on rollout A (one all-gather), then the rollout's obs_feat is
+    replaced on the device (another all-gather must happen, the stale union must not be used), two epochs on rollout B -- all
+    five epochs against the single-process oracle, which sees A, A, A, B, B."""
+    import simgan_amd as sg
+    from simgan_amd import _lib
+    from oracle import oracle as orc
+    from helpers import assert_close
+    hp, g = prepare(world, "northstar", seed=5)
+    rng = np.random.default_rng(10)
+    featB = rng.standard_normal(g["obs_feat"].shape).astype(np.float32)
+    draws = [(rng.permutation(hp["Ne"]).astype(np.int64), rng.permutation(hp["T"] * g["Ng"]).astype(np.int64),
+              rng.random(g["alpha"].size).astype(np.float32)) for _ in range(5)]
+    dpar, dadam = g["dpar"].copy(), orc.AdamState(g["dpar"].size)
+    want = [orc.disc_update(hp["F"], hp["Hd"], dpar, dadam, g["expert"], g["obs_feat"] if e < 3 else featB, hp["B"], *draws[e]) for e in range(5)]
+
+    def rank_fn(rank, ctx):
+        ctx.set_disc_dp(False)
+        _, _, disc, ro = build_rank(sg, g, rank, ctx, hp)
+        ro.sync_to_device()
+        ro.device_resident = True
+        loader = Loader(g["expert"], hp["B"])
+        gathers = C.c_longlong(0)
+        hook = _lib.load_test().sg_test_disc_gathers
+        out, counts = [], []
+        for e in range(5):
+            if e == 3:   # a new rollout: the host mirror is rewritten and pushed (what collect() does step by step)
+                ro.obs_feat.copy_(ro.obs_feat.new_tensor(shard(featB, rank, hp["N_loc"]).reshape(tuple(ro.obs_feat.shape))))
+                ro.sync_to_device([_lib.F_OBS_FEAT])
+            out.append(disc.update_gail_dyn(loader, ro, expert_perm=draws[e][0], policy_perm=draws[e][1], alpha=draws[e][2]))
+            _lib.check_test(hook(disc.h, C.byref(gathers)))
+            counts.append(gathers.value)
+        return dict(losses=out, counts=counts, dpar=disc.get_flat_params())
+
+    res = run_ranks(world, rank_fn)
+    for r in res:
+        assert r["counts"] == [1, 1, 1, 2, 2], r["counts"]
+        assert np.array_equal(res[0]["dpar"], r["dpar"]), "replicas diverged"
+    for e in range(5):
+        assert_close(res[0]["losses"][e], want[e][0], what=f"D losses epoch {e}, world {world}")
+    assert_close(res[0]["dpar"], dpar, what=f"D weights after 5 epochs, world {world}")
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_relabel_statistics_and_count_dones_equal_world1_oracle(world):
     """(ii) the per-step return statistics of the reward relabel (float64 RunningMeanStd merge over the GLOBAL batch),
