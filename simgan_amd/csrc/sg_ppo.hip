@@ -433,7 +433,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // the two actor workgroups of a row group exchanging their head outputs inside it (k_ppo_pair).  SG_PPO_PAIR=0: two launches.
     const char* penv = getenv("SG_PPO_PAIR");
     const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
-                      lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP <= d.ldH && !a->d_dbg &&
+                      lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP + 2 <= d.ldH && !a->d_dbg &&
                       !(penv && !strcmp(penv, "0"));
     // the words the actor pairs swap live in the H1 row stacks: an update that ran the two-launch step left activations there,
     // and a bit pattern must never be mistaken for a tagged word -- clear them whenever the mode is (re-)entered

@@ -294,8 +294,11 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
             // carry this step's tag -- no store drain, no separate flag, no second round trip for the data behind a flag.  The
             // words live in the H1 row stacks, which the fused body does not use (2 Pp <= ldH: checked by the launch).
             float* Ooth = t == 1 ? O0 : O1;
-            unsigned long long* xown = reinterpret_cast<unsigned long long*>(a.H1[t] + (size_t)row0 * ldH);
-            const unsigned long long* xoth = reinterpret_cast<const unsigned long long*>(a.H1[1 - t] + (size_t)row0 * ldH);
+            // (8-byte aligned: the stacks start at whatever float offset the epoch copy ends on, and a word that straddles an
+            // 8-byte boundary is two stores -- a reader could see this step's tag beside the previous step's value)
+            auto word_base = [](float* p) { return reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(p) + 7) & ~(uintptr_t)7); };
+            unsigned long long* xown = word_base(a.H1[t] + (size_t)row0 * ldH);
+            const unsigned long long* xoth = word_base(a.H1[1 - t] + (size_t)row0 * ldH);
             const int Pown = tr.Pp, Poth = d.trunk[1 - t].Pp;
             for (int i = tid; i < R * Pown; i += blockDim.x) {
                 const int r = i / Pown, c = i - r * Pown;
