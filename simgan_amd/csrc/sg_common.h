@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/simgan_hip.h"
@@ -112,6 +113,7 @@ struct sg_ctx {
     int rank = 0, world = 1;
     bool disc_sharded = false;    // SG_DISC_DP=sharded: all-reduce D gradients per step instead of replicating D
     bool use_comm = false;        // issue the data-parallel collectives (world > 1, or forced for a 1-rank self-test)
+    std::atomic<int> n_learners{0};   // live sg_ppo / sg_disc objects of this context (sg_ctx_exclusive)
     // scratch
     float* d_scratch = nullptr;   // generic device scratch (host<->device staging for API calls)
     size_t scratch_bytes = 0;
@@ -126,6 +128,17 @@ struct sg_ctx {
 };
 #define SG_RESULT_SLOTS 8
 
+// The launches that wait inside themselves (k_disc_step4, k_ppo_pair) assume that ALL their workgroups become resident: the
+// chip dispatches a grid's workgroups XCD by XCD, each XCD in index order on its own, so when another grid competes for the
+// CUs a waiting workgroup can hold the slot that the workgroup it waits for needs on another XCD (two such grids can block
+// each other until their spins time out; seen with 8 processes sharing one GPU).  With the device to itself -- one process per
+// GPU, the deployment this library is built for -- every workgroup of those grids is resident at once and the hazard does not
+// exist.  false: more than one context of this process owns learner objects (sg_ppo / sg_disc) on the device, or the
+// context's communicator is the loopback transport (ranks of one host, typically sharing a device): the callers then use the
+// multi-launch forms.  (Other processes on the device cannot be seen from here: SG_DISC_FUSED=0 / SG_PPO_PAIR=0.)
+bool sg_ctx_exclusive(const sg_ctx* ctx);
+void sg_ctx_learner_born(sg_ctx* ctx);   // sg_ppo_create / sg_disc_create
+void sg_ctx_learner_gone(sg_ctx* ctx);   // ... and their destroy calls
 int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out);
 int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out);
 // n <= 64 doubles device -> host / host -> device through the mailbox: a kernel reads or writes pinned host

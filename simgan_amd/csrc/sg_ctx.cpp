@@ -1,4 +1,5 @@
 // sg_ctx.cpp -- context, error reporting, scratch arenas, HIP-event profiling slots.
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +18,20 @@ void sg_set_error(const char* fmt, ...) {
 
 extern "C" const char* sg_last_error(void) { return g_err; }
 extern "C" const char* sg_version(void) { return "simgan_hip 0.1 (gfx950)"; }
+
+// contexts of this process, per device, that own at least one learner object (sg_ppo / sg_disc): the objects whose updates may
+// pick a launch that waits inside itself
+static std::atomic<int> g_learner_ctx[64];
+
+void sg_ctx_learner_born(sg_ctx* ctx) {
+    if (ctx->n_learners.fetch_add(1, std::memory_order_relaxed) == 0) g_learner_ctx[ctx->device & 63].fetch_add(1, std::memory_order_relaxed);
+}
+void sg_ctx_learner_gone(sg_ctx* ctx) {
+    if (ctx->n_learners.fetch_sub(1, std::memory_order_relaxed) == 1) g_learner_ctx[ctx->device & 63].fetch_sub(1, std::memory_order_relaxed);
+}
+bool sg_ctx_exclusive(const sg_ctx* ctx) {
+    return g_learner_ctx[ctx->device & 63].load(std::memory_order_relaxed) <= 1 && (ctx->world <= 1 || sg_comm_graph_ok(ctx));
+}
 
 extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     SG_REQUIRE(out != nullptr, "sg_ctx_create: out is NULL");

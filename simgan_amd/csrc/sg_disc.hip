@@ -294,6 +294,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     st.lr = 1e-3f;
     SG_CHECK(hipMemcpyAsync(d->d_state, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
+    sg_ctx_learner_born(ctx);
     *out = d;
     return 0;
 }
@@ -301,6 +302,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
+    sg_ctx_learner_gone(d->ctx);
     float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT, d->d_erows, d->d_prows};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
@@ -584,8 +586,10 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const int n_wgrad_blocks = (wa.xcd_map ? 8 * (th_ + tf_) : n_tiles + n_vec) + n_gather_wgrad;
     // one launch per step (k_disc_step4) whenever the 4-row kernel runs a full, unsharded batch; SG_DISC_FUSED=0: two launches
     const char* fenv = getenv("SG_DISC_FUSED");
+    // ... and the device is this context's alone (sg_ctx_exclusive: a launch that waits inside itself needs all its workgroups
+    // resident); SG_DISC_FUSED=1 forces it (tests), =0 forbids it
     const bool fused = thin && !sharded && !owned && !d->d_dbg && wa.xcd_map && 12 * G <= SG_STEP4_MAX_FLAGS &&
-                       !(fenv && !strcmp(fenv, "0"));
+                       (fenv ? strcmp(fenv, "0") != 0 : sg_ctx_exclusive(ctx));
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
     // One epoch = zero the loss sums, gather step 0's rows, then (chain, weight gradient) per step, then commit

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
         // while the mixup half is still being computed.  Waves take 16-row chunks round-robin, two chunks (16 loads per
         // lane) per batch; at batch 128 this is the chunk order of k_disc_wgrad, so the sums are bit-identical to it.
         const unsigned want = (unsigned)(t0 + c_k1);
-        if (!(SG_ABL & 1) && wave == 7 && !sg_step4_wait(flags, 4 * c_G, n_chain, want, lane) && lane == 0) *sh_ok = 0;
+        // (a time-out is sticky: once the error word is up, the waiting workgroups of every later launch give up at once instead
+        // of spinning out their own three seconds -- the update ends in its normal time, with NaN losses and the error reported)
+        if (!(SG_ABL & 1) && wave == 7 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || !sg_step4_wait(flags, 4 * c_G, n_chain, want, lane)) && lane == 0) *sh_ok = 0;
         __syncthreads();
         if (!*sh_ok) { if (tid == 0) { atomicOr(err, 1u); a.loss_acc[0] = __builtin_nanf(""); } return; }   // the host sees NaN losses, then the error word
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, alt = acc;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
         const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(c_part, 0, nparts * stride * 4, 0x00020000);
         if (tid == 0) *sh_ok = 1;
         __syncthreads();
-        if (!(SG_ABL & 1) && wave == 7 && !sg_step4_wait(flags, 0, n_chain, (unsigned)(t0 + c_k1), lane) && lane == 0) *sh_ok = 0;
+        if (!(SG_ABL & 1) && wave == 7 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || !sg_step4_wait(flags, 0, n_chain, (unsigned)(t0 + c_k1), lane)) && lane == 0) *sh_ok = 0;
         __syncthreads();
         if (!*sh_ok) { if (tid == 0) { atomicOr(err, 1u); a.loss_acc[0] = __builtin_nanf(""); } return; }   // the host sees NaN losses, then the error word
         float g = 0.f;

@@ -168,6 +168,7 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
     st.lr = cfg->lr;
     SG_CHECK(hipMemcpyAsync(a->d_state, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
+    sg_ctx_learner_born(ctx);
     *out = a;
     return 0;
 }
@@ -175,6 +176,7 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
 extern "C" int sg_ppo_destroy(sg_ppo* a) {
     if (!a) return 0;
     (void)hipStreamSynchronize(a->ctx->stream);
+    sg_ctx_learner_gone(a->ctx);
     float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (a->d_perms) (void)hipFree(a->d_perms);
@@ -434,7 +436,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const char* penv = getenv("SG_PPO_PAIR");
     const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
                       lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP + 2 <= d.ldH && !a->d_dbg &&
-                      !(penv && !strcmp(penv, "0"));
+                      (penv ? strcmp(penv, "0") != 0 : sg_ctx_exclusive(ctx));   // (=1 forces it on a shared device: tests)
     // the words the actor pairs swap live in the H1 row stacks: an update that ran the two-launch step left activations there,
     // and a bit pattern must never be mistaken for a tagged word -- clear them whenever the mode is (re-)entered
     if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));

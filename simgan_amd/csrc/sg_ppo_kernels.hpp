@@ -305,9 +305,10 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
                 const unsigned long long w = ((unsigned long long)pair_tag << 32) | (unsigned long long)__float_as_uint(Oown[r * ldP + c]);
                 __hip_atomic_store(xown + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            bool ok = true;
+            // (a time-out is sticky: with the error word up, the actors of every later launch skip the wait)
+            bool ok = __hip_atomic_load(a.pair + SG_PAIR_ERR_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
             const long long deadline = wall_clock64() + SG_PAIR_TIMEOUT_TICKS;
-            for (int i = tid; i < R * Poth; i += blockDim.x) {
+            for (int i = tid; ok && i < R * Poth; i += blockDim.x) {
                 const int r = i / Poth, c = i - r * Poth;
                 unsigned long long w = 0;
                 for (int it = 0;; ++it) {

@@ -295,13 +295,53 @@ def test_one_launch_step_is_bit_identical_to_the_two_launch_step(world):
     assert np.abs(p1 - p0).max() > 1e-2
 
 
-def test_one_launch_step_hand_off_under_load(world):
-    """The same comparison while the GPU is shared unevenly: six contexts on threads run the one-launch epoch at the same
-    time (their workgroups interleave on the CUs, flags and data race through a loaded fabric) and each must reproduce the
-    two-launch result of an idle GPU bit for bit.  (A hand-off whose flag can overtake its data passes on an idle chip and
-    fails here: the store drain in front of the flag was first missing, and this is how it showed.)"""
+def _run_under_load(world, subject, n_noise=5):
+    """subject(ctx) on a context of its own while `n_noise` other contexts keep the chip and the fabric busy with kernels that
+    never wait for anything (policy evaluation on 16k rows, host buffers up and down every call).  A launch that waits inside
+    itself must not share the device with ANOTHER such launch (two of them can hold the slots each other's workgroups need
+    until their spins time out: csrc/sg_common.h, sg_ctx_exclusive -- the library then uses the multi-launch forms on its own),
+    so the load here is of the kind that can only delay, and the one-launch form is forced on for the subject."""
     import threading
-    sg, _lib, ro = world["sg"], world["_lib"], world["ro"]
+    sg, _lib = world["sg"], world["_lib"]
+    stop, errs, out = threading.Event(), [], [None]
+    rng = np.random.default_rng(5)
+    obs = rng.standard_normal((16384, O)).astype(np.float32)
+    act = rng.standard_normal((16384, A)).astype(np.float32)
+
+    def noise(i):
+        try:
+            ctx = _lib.Context(0)
+            pol = sg.Policy((O,), Box((A,)), base_kwargs={"recurrent": False, "hidden_size": H}, seed=40 + i, ctx=ctx)
+            while not stop.is_set():
+                pol.evaluate_actions(obs, None, None, act)
+        except Exception as e:  # noqa: BLE001
+            errs.append("noise: " + repr(e))
+
+    def subj():
+        try:
+            out[0] = subject(_lib.Context(0))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=noise, args=(i,)) for i in range(n_noise)]
+    [t.start() for t in th]
+    ts = threading.Thread(target=subj)
+    ts.start()
+    ts.join(900)
+    stop.set()
+    [t.join(60) for t in th]
+    assert not errs, errs
+    assert out[0] is not None, "the subject did not finish"
+    return out[0]
+
+
+def test_one_launch_step_hand_off_under_load(world):
+    """The same comparison while the GPU is shared unevenly: five other contexts keep it busy while one context runs the
+    one-launch epoch three times; each run must reproduce the two-launch result of an idle GPU bit for bit.  (A hand-off whose
+    flag can overtake its data passes on an idle chip and fails under load: the store drain in front of the flag was first
+    missing, and this is how it showed.)"""
+    import os
+    sg, ro = world["sg"], world["ro"]
     rng = np.random.default_rng(78)
     steps = 192
     expert = world["expert"][:steps * B]
@@ -311,38 +351,60 @@ def test_one_launch_step_hand_off_under_load(world):
     p0 = sg.algo.gail.Discriminator(F, HD, None, seed=6).get_flat_params()
     want_l, want_p, _ = _disc_epoch(sg, ro, expert, eperm, pperm, alpha, p0, fused=False)
     feat = ro.obs_feat.numpy().copy()
-    import os
+
+    def subject(ctx):
+        r = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F, ctx=ctx)
+        r.obs_feat.copy_(r.obs_feat.new_tensor(feat))
+        res = []
+        for _ in range(3):
+            D = sg.algo.gail.Discriminator(F, HD, None, ctx=ctx, seed=11)
+            D.set_flat_params(p0)
+            ls = D.update_gail_dyn(Loader(expert, B), r, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
+            res.append((np.asarray(ls, dtype=np.float64), D.get_flat_params()))
+        return res
+
     os.environ["SG_DISC_FUSED"] = "1"
-    n_threads, rounds = 6, 3
-    out, errs = [None] * n_threads, []
-
-    def work(i):
-        try:
-            ctx = _lib.Context(0)
-            r = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F, ctx=ctx)
-            r.obs_feat.copy_(r.obs_feat.new_tensor(feat))
-            res = []
-            for _ in range(rounds):
-                D = sg.algo.gail.Discriminator(F, HD, None, ctx=ctx, seed=11)
-                D.set_flat_params(p0)
-                ls = D.update_gail_dyn(Loader(expert, B), r, expert_perm=eperm, policy_perm=pperm, alpha=alpha)
-                res.append((np.asarray(ls, dtype=np.float64), D.get_flat_params()))
-            out[i] = res
-        except Exception as e:  # noqa: BLE001
-            errs.append(repr(e))
-
     try:
-        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-        [t.start() for t in th]
-        [t.join(600) for t in th]
+        res = _run_under_load(world, subject)
     finally:
         os.environ.pop("SG_DISC_FUSED", None)
-    assert not errs, errs
-    for i, res in enumerate(out):
-        assert res is not None, f"thread {i} did not finish"
-        for ls, p in res:
-            assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
-            assert np.array_equal(ls, want_l)
+    for ls, p in res:
+        assert np.array_equal(p, want_p), f"{(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
+        assert np.array_equal(ls, want_l)
+
+
+def test_one_launch_forms_are_left_to_contexts_that_have_the_device_to_themselves(world):
+    """Two contexts of one process that both own learner objects on one device: neither may pick a launch that waits inside itself
+    (two such launches can block each other: csrc/sg_common.h, sg_ctx_exclusive).  With the switches unset the library takes the
+    two-launch step on its own for the second context (the module's fixtures live on the default one), and goes back to the
+    one-launch step for the default context once the other's objects are gone; the profiling slots say which ran."""
+    sg, _lib, lib = world["sg"], world["_lib"], world["lib"]
+    import os
+    assert "SG_DISC_FUSED" not in os.environ and "SG_PPO_PAIR" not in os.environ
+    rng = np.random.default_rng(79)
+    steps = 8
+    expert = world["expert"][:steps * B]
+    feat = world["ro"].obs_feat.numpy().copy()
+
+    def step_launches(ctx):
+        r = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F, ctx=ctx)
+        r.obs_feat.copy_(r.obs_feat.new_tensor(feat))
+        D = sg.algo.gail.Discriminator(F, HD, None, ctx=ctx, seed=11)
+        ctx.profile_reset()
+        ctx.profile(True)
+        D.update_gail_dyn(Loader(expert, B), r, expert_perm=rng.permutation(steps * B).astype(np.int64),
+                          policy_perm=rng.permutation(T * N).astype(np.int64), alpha=rng.random(steps * B).astype(np.float32))
+        ctx.profile(False)
+        return ctx.profile_read(7)[1], ctx.profile_read(0)[1]   # launches of k_disc_step4, of k_disc_chain4
+
+    import gc
+    other = _lib.Context(0)          # a second context with a discriminator of its own: nobody is alone any more
+    one, chain = step_launches(other)
+    assert (one, chain) == (0, steps), (one, chain)
+    gc.collect()                     # (its rollout and discriminator were locals of step_launches: gone)
+    solo = _lib.Context.default()
+    one, chain = step_launches(solo)
+    assert (one, chain) == (steps, 0), (one, chain)
 
 
 # ------------------------------------------------------------------ SplitPolicy: one launch per PPO step (k_ppo_pair)
@@ -402,49 +464,37 @@ def test_one_launch_split_ppo_step_is_bit_identical_to_the_two_launch_step(world
 
 
 def test_one_launch_split_ppo_step_under_load(world):
-    """The same comparison with six contexts on threads running the one-launch update at the same time: the pairs'
-    workgroups interleave with other contexts' on the CUs, and every context must reproduce the two-launch result of an idle
-    GPU bit for bit (no deadlock of a pair whose halves are dispatched apart, no flag overtaking its data)."""
+    """The same comparison while five other contexts keep the GPU busy: the pair launch, forced on for one context, must
+    reproduce the two-launch result of an idle GPU bit for bit, three updates in a row (no flag overtaking its data, no torn
+    word)."""
     import os
-    import threading
     sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
     c = PAIR_CASES[0]
     ro, p0, perms = _pair_problem(world, c, 92)
     want_l, want_p, _ = _ppo_update_split(sg, lib, _lib, c, p0, perms, pair=False, ro=ro)
     fields = {k: getattr(ro, k).numpy().copy() for k in ("obs", "actions", "value_preds", "returns", "action_log_probs", "masks")}
+
+    def subject(ctx):
+        r = sg.RolloutStorage(T, c["N"], (c["O"],), Box((c["A"],)), 1, 4, ctx=ctx)
+        for k, v in fields.items():
+            getattr(r, k).copy_(getattr(r, k).new_tensor(v))
+        res = []
+        for _ in range(3):
+            pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31, ctx=ctx)
+            pol.set_flat_params(p0)
+            agent = sg.algo.PPO(pol, 0.2, c["E"], c["M"], 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+            ls = agent.update(r, perms=perms)
+            res.append((np.asarray(ls, dtype=np.float64), pol.get_flat_params()))
+        return res
+
     os.environ["SG_PPO_PAIR"] = "1"
-    n_threads, rounds = 6, 3
-    out, errs = [None] * n_threads, []
-
-    def work(i):
-        try:
-            ctx = _lib.Context(0)
-            r = sg.RolloutStorage(T, c["N"], (c["O"],), Box((c["A"],)), 1, 4, ctx=ctx)
-            for k, v in fields.items():
-                getattr(r, k).copy_(getattr(r, k).new_tensor(v))
-            res = []
-            for _ in range(rounds):
-                pol = sg.SplitPolicy((c["O"],), Box((c["A"],)), base_kwargs={"hidden_size": c["H"], "num_feet": c["f"]}, seed=31, ctx=ctx)
-                pol.set_flat_params(p0)
-                agent = sg.algo.PPO(pol, 0.2, c["E"], c["M"], 0.5, 0.01, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
-                ls = agent.update(r, perms=perms)
-                res.append((np.asarray(ls, dtype=np.float64), pol.get_flat_params()))
-            out[i] = res
-        except Exception as e:  # noqa: BLE001
-            errs.append(repr(e))
-
     try:
-        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-        [t.start() for t in th]
-        [t.join(600) for t in th]
+        res = _run_under_load(world, subject)
     finally:
         os.environ.pop("SG_PPO_PAIR", None)
-    assert not errs, errs
-    for i, res in enumerate(out):
-        assert res is not None, f"thread {i} did not finish"
-        for ls, p in res:
-            assert np.array_equal(p, want_p), f"thread {i}: {(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
-            assert np.array_equal(ls, want_l)
+    for ls, p in res:
+        assert np.array_equal(p, want_p), f"{(p != want_p).sum()} weights differ, worst {np.abs(p - want_p).max():.3g}"
+        assert np.array_equal(ls, want_l)
 
 
 def test_one_launch_split_ppo_step_after_two_launch_updates_of_the_same_agent(world):
