@@ -38,6 +38,9 @@ struct Step4Args {          // not preloaded: read by the workgroups that copy t
 #ifndef SG_STEP4_STAMPS
 #define SG_STEP4_STAMPS 0
 #endif
+#ifndef SG_STEP4_WSTORE
+#define SG_STEP4_WSTORE 0     // how the tile blocks store the new weights: 0 streaming (kept), 1 write-through, 2 plain (A/B, round 4)
+#endif
 #if SG_STEP4_STAMPS
 #define SG_STAMP(var) const long long var = wall_clock64()
 #else
@@ -232,11 +235,21 @@ __global__ __launch_bounds__(512) void k_disc_step4(float* c_params, float* c_m,
             const float denom = sqrtf(v0) / bc2_sqrt + SG_DISC_ADAM_EPS;
             p0 = p0 - step_size * (m0 / denom);
             __builtin_amdgcn_sched_barrier(0);
+#if SG_STEP4_WSTORE == 1      // write-through (sc1) stores for what the next launch's chain blocks read
+            __hip_atomic_store(c_params + idx, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_nontemporal_store(m0, c_m + idx);
+            __builtin_nontemporal_store(v0, c_v + idx);
+            __hip_atomic_store(c_wT + img0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c_wT + img1, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif SG_STEP4_WSTORE == 2    // plain stores: written back by the end-of-kernel release
+            c_params[idx] = p0; c_m[idx] = m0; c_v[idx] = v0; c_wT[img0] = p0; c_wT[img1] = p0;
+#else
             __builtin_nontemporal_store(p0, c_params + idx);
             __builtin_nontemporal_store(m0, c_m + idx);
             __builtin_nontemporal_store(v0, c_v + idx);
             __builtin_nontemporal_store(p0, c_wT + img0);
             __builtin_nontemporal_store(p0, c_wT + img1);
+#endif
         }
         return;
     }
