@@ -586,7 +586,8 @@ def main():
                                        "LOOPBACK self-test (shared-memory transport, ranks share a device): exercises the N > 1 code "
                                        "path, NOT a scaling measurement"),
                            "kind": kind, "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
-                           "disc_mode": "sharded" if ctx.disc_sharded else "replicated"}
+                           "disc_mode": "sharded" if ctx.disc_sharded else "replicated",
+                           "peer_allreduce": ctx.comm_peer()}   # SG_COMM_PEER=1: the per-step gradient all-reduce as one peer-write kernel
     else:
         out = None
     # N > 1: the discriminator has two data-parallel modes.  `value` is the default (replicated:

@@ -61,7 +61,9 @@ SG_API int sg_comm_unique_id(uint8_t id[128]);
  * synchronises the stream per collective and is not a performance path. */
 SG_API int sg_comm_loopback_id(uint8_t id[128]);
 SG_API int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int world);
-/* *kind = 0 no communicator, 1 RCCL, 2 loopback. */
+/* *kind = 0 no communicator, 1 RCCL, 2 loopback; + 4 when the per-step float32 gradient all-reduces run as one kernel over
+ * peer-mapped device memory instead of a library collective (SG_COMM_PEER=1 in the environment at sg_ctx_comm_init: opt-in,
+ * built over either transport). */
 SG_API int sg_ctx_comm_kind(sg_ctx *ctx, int *kind);
 /* rank / world as the communicator itself reports them (ncclCommUserRank / ncclCommCount) once it exists. */
 SG_API int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);

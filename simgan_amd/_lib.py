@@ -257,7 +257,13 @@ class Context:
         """'none' | 'rccl' | 'loopback'"""
         k = C.c_int(0)
         check(self.lib.sg_ctx_comm_kind(self.h, C.byref(k)))
-        return ("none", "rccl", "loopback")[k.value]
+        return ("none", "rccl", "loopback")[k.value & 3]
+
+    def comm_peer(self):
+        """True when the small float32 all-reduces run over the peer mesh (SG_COMM_PEER=1 at comm_init)."""
+        k = C.c_int(0)
+        check(self.lib.sg_ctx_comm_kind(self.h, C.byref(k)))
+        return bool(k.value & 4)
 
     def comm_info(self):
         """(rank, world) as the communicator itself reports them."""

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <vector>
 
 #include "sg_common.h"
 
@@ -73,9 +74,45 @@ struct SgLoopback {
     double timeout_s = 120.0;
 };
 
+// ------------------------------------------------------------------------------------------- peer mesh (SG_COMM_PEER=1)
+// The small float32 all-reduce of an optimizer step (one per PPO step, one per sharded discriminator step: 60-300 KB, 160 to
+// thousands of times per update) as ONE kernel over peer-mapped device memory instead of a library collective (SURVEY.md
+// section 5 "one-shot peer-write all-reduce"): every rank owns a slot buffer that all ranks have mapped (hipIpc between
+// processes, the plain pointer between contexts of one process); a collective is
+//     each workgroup: write its chunk of the rank's vector into EVERY rank's slot [parity][rank] (system-scope stores),
+//                     drain them, raise its flag word [parity][rank][workgroup] on every rank,
+//                     wait for the `world` flag words of its chunk in its OWN buffer, add the `world` slots in rank order
+// -- one launch, no host involvement, capturable into a hipGraph, bit-identical on every rank (fixed order, the loopback
+// transport's order).  The wait is one-way per rank pair and bounded by the wall clock; slots and flags are double-buffered by
+// the parity of the collective's number, which is enough because no rank can start collective s + 2 before every rank has
+// finished reading collective s (it has seen their flags of s + 1).  The base communicator (RCCL or loopback) stays for set-up
+// (the exchange of the memory handles is one all-gather over it), the float64 statistics and the all-gather.
+// OPT-IN and, across GPUs, UNTESTED: a gpurun box has one GPU, so what runs there is ranks sharing a device (threads: plain
+// pointers; processes: hipIpc handles) -- the same kernel and protocol, local HBM instead of xGMI.
+#define SG_PEER_MAX_WORLD 16
+#define SG_PEER_MAX_BLOCKS 128                  // = SG_PEER_MAX_FLOATS / 1024: one workgroup per 1024 floats
+#define SG_PEER_MAX_FLOATS (128 * 1024)      // per rank and collective: 512 KB
+#define SG_PEER_FLAG_STRIDE 32               // words: one 128-byte line per flag
+#define SG_PEER_TIMEOUT_TICKS 2000000000ll   // 20 s of the 100 MHz wall clock: a peer may be a whole kernel queue behind
+
+struct SgPeerDev {                           // kernel argument, by value
+    float* slots[SG_PEER_MAX_WORLD];         // rank r's slot buffer as mapped HERE: [2][world][SG_PEER_MAX_FLOATS]
+    unsigned* flags[SG_PEER_MAX_WORLD];      // rank r's flag words as mapped here: [2][world][SG_PEER_MAX_BLOCKS] lines
+    unsigned* ctrl;                          // own: {collectives completed, -, error}
+    int rank, world;
+};
+
+struct SgPeer {
+    SgPeerDev dev;
+    void* own = nullptr;                     // this rank's allocation (slots | flags | ctrl)
+    void* mapped[SG_PEER_MAX_WORLD] = {nullptr};   // hipIpcOpenMemHandle results (other processes' buffers)
+    uint64_t launches = 0;
+};
+
 struct SgComm {
     ncclComm_t comm = nullptr;
     SgLoopback* lb = nullptr;
+    SgPeer* peer = nullptr;
 };
 
 static double lb_now() {
@@ -284,6 +321,184 @@ extern "C" int sg_comm_loopback_id(uint8_t id[128]) {
     return 0;
 }
 
+// system-scope (sc0 sc1) accesses: past every cache of this GPU and of the peer
+typedef unsigned int sg_pu4 __attribute__((ext_vector_type(4)));
+#define SG_PEER_AUX 17   // sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_peer_rsrc(const float* p, int floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, floats * 4, 0x00020000);
+}
+
+// grid = ceil(n / 1024) workgroups of 256 lanes: every lane owns ONE 16-byte piece of the vector (n4 = n / 4 whole pieces;
+// the 0..3 floats of a ragged tail go through lane 0 of the last workgroup one by one)
+__global__ __launch_bounds__(256) void k_peer_allreduce(SgPeerDev P, float* buf, int n) {
+    __shared__ int sh_ok;
+    const int b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x, W = P.world, me = P.rank;
+    // collectives completed so far: committed by workgroup 0 of the previous collective once all of that launch's workgroups
+    // had read it (see 6.), and behind a kernel boundary
+    const unsigned s = __hip_atomic_load(P.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int par = (int)(s & 1u);
+    const int n4 = n >> 2, i4 = b * 256 + tid;
+    const bool mine = i4 < n4, tail = (n & 3) != 0 && b == nb - 1 && tid == 0;
+    // 1. this rank's piece into every rank's slot [par][me] (own slot included: the sum below reads slots only)
+    sg_pu4 v = sg_pu4{0u, 0u, 0u, 0u};
+    if (mine) v = __builtin_amdgcn_raw_buffer_load_b128(sg_peer_rsrc(buf, n4 * 4), i4 * 16, 0, 0);
+    for (int q = 0; q < W; ++q) {
+        const int r = (me + 1 + q) % W;      // start with the neighbour: the ranks do not all hit rank 0's memory first
+        float* dst = P.slots[r] + ((size_t)(par * W + me)) * SG_PEER_MAX_FLOATS;
+        if (mine) __builtin_amdgcn_raw_buffer_store_b128(v, sg_peer_rsrc(dst, n4 * 4), i4 * 16, 0, SG_PEER_AUX);
+        if (tail) for (int i = n4 * 4; i < n; ++i) __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 2. the stores are acknowledged before the flag is raised (spelt out: a barrier alone implies no vmcnt wait on gfx950)
+    //    (no __threadfence_system(): the stores above ARE system-scope write-through stores, and a fence would write back and
+    //    invalidate this XCD's whole L2 once per workgroup -- measured: 10 us per collective at 55 workgroups instead of 4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) sh_ok = 1;
+    __syncthreads();
+    // 3. one flag word per (parity, writer, workgroup) on every rank
+    if (tid < W) __hip_atomic_store(P.flags[tid] + ((size_t)(par * W + me) * SG_PEER_MAX_BLOCKS + b) * SG_PEER_FLAG_STRIDE, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 4. wait for every rank's piece b in this rank's own buffer
+    if (tid < W) {
+        const unsigned* f = P.flags[me] + ((size_t)(par * W + tid) * SG_PEER_MAX_BLOCKS + b) * SG_PEER_FLAG_STRIDE;
+        const long long deadline = wall_clock64() + SG_PEER_TIMEOUT_TICKS;
+        for (int it = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != s; ++it) {
+            if (__hip_atomic_load(P.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ((it & 63) == 63 && wall_clock64() > deadline)) { sh_ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    // 5. the sum in rank order, all `world` loads in flight (a time-out leaves NaN and raises the error word: sticky, later
+    //    collectives give up at once)
+    const float* src = P.slots[me] + (size_t)par * W * SG_PEER_MAX_FLOATS;
+    if (sh_ok) {
+        if (mine) {
+            sg_pu4 x[SG_PEER_MAX_WORLD];
+#pragma unroll
+            for (int r = 0; r < SG_PEER_MAX_WORLD; ++r)
+                if (r < W) x[r] = __builtin_amdgcn_raw_buffer_load_b128(sg_peer_rsrc(src + (size_t)r * SG_PEER_MAX_FLOATS, n4 * 4), i4 * 16, 0, SG_PEER_AUX);
+            float a0 = __uint_as_float(x[0].x), a1 = __uint_as_float(x[0].y), a2 = __uint_as_float(x[0].z), a3 = __uint_as_float(x[0].w);
+#pragma unroll
+            for (int r = 1; r < SG_PEER_MAX_WORLD; ++r)
+                if (r < W) { a0 += __uint_as_float(x[r].x); a1 += __uint_as_float(x[r].y); a2 += __uint_as_float(x[r].z); a3 += __uint_as_float(x[r].w); }
+            *reinterpret_cast<float4*>(buf + (size_t)i4 * 4) = float4{a0, a1, a2, a3};
+        }
+        if (tail)
+            for (int i = n4 * 4; i < n; ++i) {
+                float acc = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int r = 1; r < W; ++r) acc += __hip_atomic_load(src + (size_t)r * SG_PEER_MAX_FLOATS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                buf[i] = acc;
+            }
+    } else {
+        const float qnan = __builtin_nanf("");
+        if (mine) *reinterpret_cast<float4*>(buf + (size_t)i4 * 4) = float4{qnan, qnan, qnan, qnan};
+        if (tail) for (int i = n4 * 4; i < n; ++i) buf[i] = qnan;
+        if (tid == 0) atomicOr(P.ctrl + 2, 1u);
+    }
+    // 6. workgroup 0 commits the collective's number -- once every workgroup of this launch has raised its own flag on this
+    //    rank, i.e. has read the old number (no read-modify-write on a shared word: 60 of those cost microseconds).  A timed-out
+    //    launch commits as well, so that the numbering stays aligned with the ranks that did not time out.
+    if (b == 0 && tid < 64) {
+        const long long deadline = wall_clock64() + SG_PEER_TIMEOUT_TICKS;
+        for (int it = 0;; ++it) {
+            bool ok = true;
+            for (int j = tid; j < nb; j += 64)
+                ok = ok & (__hip_atomic_load(P.flags[me] + ((size_t)(par * W + me) * SG_PEER_MAX_BLOCKS + j) * SG_PEER_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == s);
+            if (__all(ok) || ((it & 63) == 63 && wall_clock64() > deadline)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (tid == 0) __hip_atomic_store(P.ctrl, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+struct SgPeerRecord {            // what the ranks tell each other about their buffers: 24 floats' worth of bytes
+    hipIpcMemHandle_t handle;    // 64 bytes
+    uint64_t pid, ptr;
+    int32_t device, pad[3];
+};
+static_assert(sizeof(SgPeerRecord) == 96, "SgPeerRecord travels as 24 floats");
+
+static void peer_release(sg_ctx* ctx, SgPeer* p) {
+    (void)hipSetDevice(ctx->device);
+    for (int r = 0; r < SG_PEER_MAX_WORLD; ++r) if (p->mapped[r]) (void)hipIpcCloseMemHandle(p->mapped[r]);
+    if (p->own) (void)hipFree(p->own);
+    delete p;
+}
+
+// Builds the mesh over the base communicator that is already up.  Every rank must call it (it contains a collective).
+static int peer_setup(sg_ctx* ctx) {
+    const int W = ctx->world, me = ctx->rank;
+    SG_REQUIRE(W <= SG_PEER_MAX_WORLD, "SG_COMM_PEER: at most %d ranks (world is %d)", SG_PEER_MAX_WORLD, W);
+    const size_t slot_b = sizeof(float) * 2 * (size_t)W * SG_PEER_MAX_FLOATS;
+    const size_t flag_b = sizeof(unsigned) * 2 * (size_t)W * SG_PEER_MAX_BLOCKS * SG_PEER_FLAG_STRIDE;
+    const size_t total = slot_b + flag_b + 256;
+    SgPeer* p = new SgPeer();
+    if (hipMalloc(&p->own, total) != hipSuccess) { delete p; SG_REQUIRE(false, "SG_COMM_PEER: hipMalloc of %zu bytes failed", total); }
+    int rc = 0;
+    float *d_rec = nullptr, *d_all = nullptr;
+    std::vector<SgPeerRecord> all((size_t)W);
+    do {
+        if (hipMemsetAsync(p->own, 0, total, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: clearing the slot buffer failed"); rc = -1; break; }
+        SgPeerRecord rec;
+        memset(&rec, 0, sizeof rec);
+        rec.pid = (uint64_t)getpid(); rec.ptr = (uint64_t)(uintptr_t)p->own; rec.device = ctx->device;
+        // (a handle is only needed by ranks in OTHER processes; a failure here surfaces there, when they try to open it)
+        if (hipIpcGetMemHandle(&rec.handle, p->own) != hipSuccess) { (void)hipGetLastError(); memset(&rec.handle, 0, sizeof rec.handle); }
+        if (hipMalloc((void**)&d_rec, sizeof rec) != hipSuccess || hipMalloc((void**)&d_all, sizeof rec * (size_t)W) != hipSuccess) { sg_set_error("SG_COMM_PEER: hipMalloc failed"); rc = -1; break; }
+        if (hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: upload failed"); rc = -1; break; }
+        rc = sg_comm_allgather_f32(ctx, d_rec, d_all, (int64_t)(sizeof rec / 4));
+        if (rc != 0) break;
+        if (hipMemcpyAsync(all.data(), d_all, sizeof rec * (size_t)W, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: download failed"); rc = -1; break; }
+        // Ranks that are contexts of ONE process share that process's hardware queues (HIP maps streams onto GPU_MAX_HW_QUEUES
+        // of them, 4 by default): a collective kernel that waits for the kernel of a rank whose stream sits behind it on the
+        // same queue would wait for ever.  (One process per rank -- the deployment -- has a queue set per rank.)
+        int same_pid = 0;
+        for (int r = 0; r < W; ++r) same_pid += all[(size_t)r].pid == (uint64_t)getpid();
+        const char* hq = getenv("GPU_MAX_HW_QUEUES");
+        const int n_hq = hq && atoi(hq) > 0 ? atoi(hq) : 4;
+        if (same_pid > n_hq) {
+            sg_set_error("SG_COMM_PEER: %d ranks are contexts of one process, which has %d hardware queues (GPU_MAX_HW_QUEUES): "
+                         "streams sharing a queue cannot wait for each other's kernels; use one process per rank", same_pid, n_hq);
+            rc = -2;
+        }
+        for (int r = 0; r < W && rc == 0; ++r) {
+            void* base = nullptr;
+            if (r == me) base = p->own;
+            else if (all[(size_t)r].pid == (uint64_t)getpid()) {      // a context of this process: its pointer is valid here
+                base = (void*)(uintptr_t)all[(size_t)r].ptr;
+                if (all[(size_t)r].device != ctx->device) {           // ... on another device: peer access (idempotent)
+                    const hipError_t e = hipDeviceEnablePeerAccess(all[(size_t)r].device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { sg_set_error("SG_COMM_PEER: no peer access from device %d to device %d: %s", ctx->device, all[(size_t)r].device, hipGetErrorString(e)); rc = -1; }
+                    (void)hipGetLastError();
+                }
+            } else {
+                const hipError_t e = hipIpcOpenMemHandle(&base, all[(size_t)r].handle, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) { sg_set_error("SG_COMM_PEER: hipIpcOpenMemHandle of rank %d's buffer failed: %s", r, hipGetErrorString(e)); rc = -1; (void)hipGetLastError(); }
+                else p->mapped[r] = base;
+            }
+            p->dev.slots[r] = reinterpret_cast<float*>(base);
+            p->dev.flags[r] = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(base) + slot_b);
+        }
+    } while (0);
+    if (d_rec) (void)hipFree(d_rec);
+    if (d_all) (void)hipFree(d_all);
+    if (rc != 0) { peer_release(ctx, p); return rc; }
+    p->dev.ctrl = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(p->own) + slot_b + flag_b);
+    p->dev.rank = me; p->dev.world = W;
+    ctx->comm->peer = p;
+    return 0;
+}
+
+static int peer_allreduce(sg_ctx* ctx, float* dev, int64_t n) {
+    SgPeer* p = ctx->comm->peer;
+    SG_REQUIRE(((uintptr_t)dev & 15) == 0, "peer all-reduce: the vector must be 16-byte aligned");
+    const int nb = (int)((n + 1023) / 1024);   // <= SG_PEER_MAX_BLOCKS by the caller's n <= SG_PEER_MAX_FLOATS
+    hipLaunchKernelGGL(k_peer_allreduce, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p->dev, dev, (int)n);
+    SG_CHECK(hipGetLastError());
+    p->launches += 1;
+    return 0;
+}
+
+static bool peer_wanted() { const char* e = getenv("SG_COMM_PEER"); return e && e[0] == '1'; }
+
 static void comm_common_flags(sg_ctx* ctx, int world) {
     // SG_COMM_ALWAYS=1 keeps the collectives in the launch sequence even for a single rank (where
     // they are the identity): the 1-GPU self-test of the RCCL path (tests/test_gpu_comm.py)
@@ -308,7 +523,7 @@ extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, in
         ctx->rank = rank;
         ctx->world = world;
         comm_common_flags(ctx, world);
-        return 0;
+        return peer_wanted() ? peer_setup(ctx) : 0;
     }
     SG_TRY(rccl_load());
     ncclUniqueId u;
@@ -326,7 +541,7 @@ extern "C" int sg_ctx_comm_init(sg_ctx* ctx, const uint8_t id[128], int rank, in
     SG_CHECK(hipMemsetAsync(warm, 0, 64, ctx->stream));
     SG_NCCL(g_rccl.AllReduce(warm, warm, 4, ncclFloat32, ncclSum, c->comm, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return peer_wanted() ? peer_setup(ctx) : 0;
 }
 
 extern "C" int sg_ctx_comm_info(sg_ctx* ctx, int* rank, int* world) {
@@ -360,15 +575,18 @@ extern "C" int sg_ctx_set_disc_dp(sg_ctx* ctx, int sharded) {
 // 1: RCCL (collectives are stream operations and can be captured into a hipGraph), 0: loopback (synchronises the stream)
 int sg_comm_graph_ok(const sg_ctx* ctx) { return !(ctx->comm && ctx->comm->lb); }
 
-// 0: none, 1: RCCL, 2: loopback
+// 0: none, 1: RCCL, 2: loopback; + 4: the small float32 all-reduces run over the peer mesh (SG_COMM_PEER=1)
 extern "C" int sg_ctx_comm_kind(sg_ctx* ctx, int* kind) {
     SG_REQUIRE(ctx && kind, "sg_ctx_comm_kind: NULL argument");
-    *kind = !ctx->comm ? 0 : ctx->comm->lb ? 2 : 1;
+    *kind = !ctx->comm ? 0 : (ctx->comm->lb ? 2 : 1) | (ctx->comm->peer ? 4 : 0);
     return 0;
 }
 
 void sg_comm_destroy(sg_ctx* ctx) {
     if (!ctx->comm) return;
+    // (the stream has been synchronised: this rank's last collective is complete, so no rank writes into its buffer any more
+    // -- a collective completes only when every rank's chunk has arrived, and a rank cannot start another without this one)
+    if (ctx->comm->peer) { peer_release(ctx, ctx->comm->peer); ctx->comm->peer = nullptr; }
     if (ctx->comm->lb) {
         SgLoopback* lb = ctx->comm->lb;
         if (lb->h_tmp) (void)hipHostFree(lb->h_tmp);
@@ -382,6 +600,7 @@ void sg_comm_destroy(sg_ctx* ctx) {
 
 int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n) {
     SG_REQUIRE(ctx->comm, "all-reduce requested but no communicator (call sg_ctx_comm_init)");
+    if (ctx->comm->peer && n > 0 && n <= SG_PEER_MAX_FLOATS) return peer_allreduce(ctx, dev, n);
     if (ctx->comm->lb) return lb_collective(ctx, 0, dev, dev, (size_t)n, 4);
     SG_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat32, ncclSum, ctx->comm->comm, ctx->stream));
     return 0;
