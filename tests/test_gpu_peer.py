@@ -2,7 +2,11 @@
 over peer-mapped device memory -- on one device: ranks as threads of one process (plain pointers) and as processes
 (hipIpc handles, through bench.py --loopback).  It adds the ranks' vectors in rank order, the loopback transport's order, so
 everything downstream must be BIT-identical to the same run without it, and equal to the world-1 oracle as before.
-Across GPUs (xGMI) it has never run: a gpurun box has one GPU."""
+Across GPUs (xGMI) it has never run: a gpurun box has one GPU.
+
+The thread-rank cases run in a FRESH interpreter with GPU_MAX_HW_QUEUES=8: a collective kernel waits for the other ranks'
+kernels, and streams of one process that share a hardware queue (4 by default, assigned by the runtime as it sees fit -- the
+pytest process holds streams of earlier tests) cannot wait for each other.  `python tests/test_gpu_peer.py` runs them directly."""
 import json
 import os
 import subprocess
@@ -15,14 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import test_gpu_world as tw  # noqa: E402
-
 pytestmark = pytest.mark.gpu
 
 
-def _ppo_world(world, name, peer, monkeypatch):
+def _ppo_world(tw, world, name, peer):
     import simgan_amd as sg
-    monkeypatch.setenv("SG_COMM_PEER", "1" if peer else "0")
+    os.environ["SG_COMM_PEER"] = "1" if peer else "0"
     hp, g = tw.prepare(world, name)
     next_value = np.random.default_rng(5).standard_normal(g["Ng"]).astype(np.float32)
 
@@ -36,12 +38,12 @@ def _ppo_world(world, name, peer, monkeypatch):
     return hp, g, next_value, tw.run_ranks(world, rank_fn)
 
 
-@pytest.mark.parametrize("world,name", [(2, "mlp_small"), (4, "northstar"), (3, "mlp_small"), (4, "split")])
-def test_ppo_over_the_peer_mesh_is_bit_identical_to_the_loopback_sum_and_equals_the_oracle(world, name, monkeypatch):
+def case_ppo(tw, world, name):
+    """PPO over the mesh: replicas identical, bit-identical to the loopback sum, equal to the world-1 oracle."""
     from oracle import oracle as orc
     from helpers import assert_close
-    hp, g, next_value, res = _ppo_world(world, name, True, monkeypatch)
-    _, _, _, ref = _ppo_world(world, name, False, monkeypatch)
+    hp, g, next_value, res = _ppo_world(tw, world, name, True)
+    _, _, _, ref = _ppo_world(tw, world, name, False)
     for r in res:
         assert np.array_equal(r["pi"], res[0]["pi"]) and r["losses"] == res[0]["losses"], "replicas diverged"
     assert np.array_equal(res[0]["pi"], ref[0]["pi"]) and res[0]["losses"] == ref[0]["losses"], "peer sum differs from the loopback sum"
@@ -53,14 +55,13 @@ def test_ppo_over_the_peer_mesh_is_bit_identical_to_the_loopback_sum_and_equals_
     assert_close(res[0]["pi"], pi, rtol=2e-4, atol=2e-5, what="policy after two updates")
 
 
-@pytest.mark.parametrize("world,name", [(2, "northstar"), (4, "split")])
-def test_sharded_discriminator_over_the_peer_mesh(world, name, monkeypatch):
-    """One gradient all-reduce per discriminator step (sharded mode): 8+ collectives back to back exercise the double-buffered
+def case_disc_sharded(tw, world, name):
+    """One gradient all-reduce per discriminator step (sharded mode): 12+ collectives back to back exercise the double-buffered
     slots and the collective counter."""
     import simgan_amd as sg
 
     def run(peer):
-        monkeypatch.setenv("SG_COMM_PEER", "1" if peer else "0")
+        os.environ["SG_COMM_PEER"] = "1" if peer else "0"
         hp, g = tw.prepare(world, name)
 
         def rank_fn(rank, ctx):
@@ -79,6 +80,39 @@ def test_sharded_discriminator_over_the_peer_mesh(world, name, monkeypatch):
     assert np.array_equal(res[0]["dpar"], ref[0]["dpar"]) and res[0]["losses"] == ref[0]["losses"]
 
 
+def case_refused(tw):
+    """More contexts of one process than it has hardware queues: refused at set-up with an explanation, not a time-out."""
+    os.environ["SG_COMM_PEER"] = "1"
+    os.environ["GPU_MAX_HW_QUEUES_SAVED"] = os.environ.get("GPU_MAX_HW_QUEUES", "")
+    os.environ["GPU_MAX_HW_QUEUES"] = "4"   # (read by the library's check at set-up; the runtime took its own copy at start-up)
+    try:
+        tw.run_ranks(8, lambda rank, ctx: None, timeout_s=120)
+    except AssertionError as exc:
+        assert "hardware queues" in str(exc), str(exc)
+    else:
+        raise AssertionError("8 same-process ranks on 4 hardware queues were accepted")
+    finally:
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ.pop("GPU_MAX_HW_QUEUES_SAVED") or "8"
+
+
+THREAD_CASES = [("ppo", 2, "mlp_small"), ("ppo", 3, "mlp_small"), ("ppo", 4, "northstar"), ("ppo", 4, "split"), ("ppo", 8, "northstar"),
+                ("disc_sharded", 2, "northstar"), ("disc_sharded", 4, "split"), ("refused",)]
+
+
+def main():
+    import test_gpu_world as tw
+    for case in THREAD_CASES:
+        {"ppo": case_ppo, "disc_sharded": case_disc_sharded, "refused": case_refused}[case[0]](tw, *case[1:])
+        print("OK", *case, flush=True)
+
+
+def test_thread_ranks_over_the_peer_mesh_equal_the_loopback_sums_and_the_oracle():
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", SG_LOOPBACK_TIMEOUT_S="120")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    done = [ln for ln in r.stdout.splitlines() if ln.startswith("OK ")]
+    assert r.returncode == 0 and len(done) == len(THREAD_CASES), (done, r.stdout[-1500:], r.stderr[-4000:])
+
+
 def _bench(extra_env, gpus=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SG_LOOPBACK_TIMEOUT_S="120", **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -91,21 +125,17 @@ def _bench(extra_env, gpus=2):
     return json.loads(lines[0])
 
 
-def test_ranks_in_separate_processes_map_each_other_through_hipipc():
-    """bench.py --gpus 2 --loopback: two PROCESSES on the device, their slot buffers opened through hipIpc handles that travel
-    over the base communicator's all-gather; 16 PPO steps per update, each with one peer all-reduce.  Same losses as without."""
-    a = _bench({"SG_COMM_PEER": "1"})
-    b = _bench({"SG_COMM_PEER": "0"})
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_ranks_in_separate_processes_map_each_other_through_hipipc(gpus):
+    """bench.py --gpus N --loopback: N PROCESSES on the device, their slot buffers opened through hipIpc handles that travel
+    over the base communicator's all-gather; 80 PPO steps per update, each with one peer all-reduce.  Same losses as without."""
+    a = _bench({"SG_COMM_PEER": "1"}, gpus)
+    b = _bench({"SG_COMM_PEER": "0"}, gpus)
     assert a["comm"]["peer_allreduce"] is True and b["comm"]["peer_allreduce"] is False
     assert a["replica_check"]["ok"] is True
     assert a["last_losses"] == b["last_losses"], (a["last_losses"], b["last_losses"])
     assert a["replica_check"]["weights_sha256_rank0"] == b["replica_check"]["weights_sha256_rank0"]
 
 
-def test_more_ranks_in_one_process_than_hardware_queues_are_refused(monkeypatch):
-    """Contexts of ONE process share its hardware queues (4 by default): a kernel that waits for the kernel of a stream queued
-    behind it would never finish, so the mesh refuses that set-up with an explanation instead of timing out."""
-    monkeypatch.setenv("SG_COMM_PEER", "1")
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    with pytest.raises(AssertionError, match="hardware queues"):
-        tw.run_ranks(8, lambda rank, ctx: None, timeout_s=120)
+if __name__ == "__main__":
+    main()
