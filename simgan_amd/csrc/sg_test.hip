@@ -620,3 +620,74 @@ extern "C" int sg_test_rng(sg_ctx* ctx, int kind, int64_t n, uint64_t seed, void
     (void)hipFree(dev);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tear probe (tools/tear_probe.py): can ONE lane's write-through store of W bytes be seen half-written by a lane of another
+// XCD?  Writer workgroups (XCDs 0-3) store {t, t, ...} with t = 1, 2, ... into their lanes' slots as fast as they can; reader
+// workgroups (XCDs 4-7) load the same slots with L1-bypassing loads and count the words whose dwords disagree.
+// mode 0: 16-byte word, 16-byte aligned;  1: 16-byte word at an 8-byte offset (straddles a 16-byte boundary);
+// mode 2: 8-byte word, 8-byte aligned;    3: 8-byte word at a 4-byte offset;
+// positive controls: 4: 8-byte word across a 64-byte boundary (offset 60); 5: 16-byte word across a 64-byte boundary (offset 56);
+//                    6: 16-byte word across a 128-byte line (offset 120); 7: 8-byte word across a 128-byte line (offset 124).
+// out = {torn words seen, words read, largest t seen, reader lanes that saw at least two different t}.
+typedef unsigned int sg_tu4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sg_tu2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_tear_probe(unsigned* words, int n_bytes, int iters, int mode, unsigned long long* out, unsigned* done) {
+    const int xcd = blockIdx.x & 7, tid = threadIdx.x;
+    const bool writer = xcd < 4;
+    const int pair = (int)(blockIdx.x >> 3) * 4 + (xcd & 3);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(words, 0, n_bytes, 0x00020000);
+    const int offs[8] = {0, 8, 0, 4, 60, 56, 120, 124};
+    const int off = (pair * 256 + tid) * 256 + offs[mode & 7];   // one 256-byte slot per lane
+    const bool wide = mode < 2 || mode == 5 || mode == 6;
+    if (writer) {
+        for (int t = 1; t <= iters; ++t) {
+            const unsigned u = (unsigned)t;
+            if (wide) __builtin_amdgcn_raw_buffer_store_b128(sg_tu4{u, u, u, u}, r, off, 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b64(sg_tu2{u, u}, r, off, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) atomicAdd(done, 1u);
+        return;
+    }
+    unsigned long long torn = 0, reads = 0;
+    unsigned tmax = 0, tfirst = 0, changed = 0;
+    const unsigned n_writers = gridDim.x / 2;
+    for (int it = 0;; ++it) {
+        unsigned a, b, c, d;
+        if (wide) { const sg_tu4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); a = v.x; b = v.y; c = v.z; d = v.w; }
+        else { const sg_tu2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16); a = v.x; b = v.y; c = a; d = b; }
+        reads += 1;
+        torn += (a != b) | (a != c) | (a != d);
+        const unsigned m = a > b ? a : b;
+        tmax = m > tmax ? m : tmax;
+        if (tfirst == 0 && a != 0) tfirst = a;
+        changed |= (tfirst != 0 && a != tfirst);
+        if ((it & 63) == 63 && (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_writers || it > 64 * iters)) break;
+    }
+    atomicAdd(out + 0, torn);
+    atomicAdd(out + 1, reads);
+    atomicMax(out + 2, (unsigned long long)tmax);
+    atomicAdd(out + 3, (unsigned long long)changed);
+}
+
+extern "C" int sg_test_tear_probe(sg_ctx* ctx, int mode, int pairs4, int iters, long long* out4) {
+    SG_REQUIRE(ctx && out4 && mode >= 0 && mode <= 7 && pairs4 > 0 && pairs4 <= 16 && iters > 0, "sg_test_tear_probe: bad argument");
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int n_bytes = pairs4 * 4 * 256 * 256 + 256;
+    unsigned *d_words = nullptr, *d_done = nullptr;
+    unsigned long long* d_out = nullptr;
+    SG_CHECK(hipMalloc((void**)&d_words, (size_t)n_bytes));
+    SG_CHECK(hipMalloc((void**)&d_done, 256));
+    SG_CHECK(hipMalloc((void**)&d_out, 64));
+    SG_CHECK(hipMemsetAsync(d_words, 0, (size_t)n_bytes, ctx->stream));
+    SG_CHECK(hipMemsetAsync(d_done, 0, 256, ctx->stream));
+    SG_CHECK(hipMemsetAsync(d_out, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_tear_probe, dim3(8 * pairs4), dim3(256), 0, ctx->stream, d_words, n_bytes, iters, mode, d_out, d_done);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    SG_CHECK(hipMemcpy(out4, d_out, 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d_words); (void)hipFree(d_done); (void)hipFree(d_out);
+    return 0;
+}

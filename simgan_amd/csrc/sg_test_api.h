@@ -25,6 +25,9 @@ SG_API int sg_test_ppo_phase_times(sg_ppo *a, int enable, long long *out, int n_
 /* all-gathers the discriminator's replicated data-parallel mode has issued so far (it reuses the union across the epochs of an update) */
 SG_API int sg_test_disc_gathers(sg_disc *d, long long *out);
 /* kind 0: permutation of [0, n) -> int64 out; 1: uniform [0,1) -> float out; 2: standard normal -> float out */
+/* one lane's write-through store of 16 / 8 bytes (aligned, or straddling its own size) read from another XCD: out4 = {torn words,
+ * words read, largest value seen, reader lanes that saw the value change} (tools/tear_probe.py) */
+SG_API int sg_test_tear_probe(sg_ctx *ctx, int mode, int pairs4, int iters, long long *out4);
 SG_API int sg_test_rng(sg_ctx *ctx, int kind, int64_t n, uint64_t seed, void *out);
 #ifdef __cplusplus
 }
