@@ -94,6 +94,15 @@ static void launch_disc_step4(sg_ctx* ctx, const SgDiscDesc& dd, sg_disc* d, flo
     else SG_STEP4(1, 1);
 #undef SG_STEP4
 }
+// When a weight-gradient wave of k_disc_step4 first asks for the BCE half / the mixup half of its operands, in 10 ns ticks
+// after its workgroup's start (sg_disc_step4.hpp; measured with tools/step4_times.py).  SG_STEP4_TA / SG_STEP4_TB override.
+static void sg_step4_poll_times(const SgDiscDesc& dd, int* ta, int* tb) {
+    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
+    *ta = (kf == 6 && kh == 7) ? 300 : (kf == 2 && kh == 7) ? 240 : 0;
+    *tb = (kf == 6 && kh == 7) ? 370 : (kf == 2 && kh == 7) ? 300 : 0;
+    if (const char* e = getenv("SG_STEP4_TA")) *ta = atoi(e);
+    if (const char* e = getenv("SG_STEP4_TB")) *tb = atoi(e);
+}
 static void disc_refresh_images(sg_disc* d) {
     hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
 }
@@ -284,8 +293,8 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
         SG_CHECK(hipStreamSynchronize(ctx->stream));
     }
     const size_t wT_f = (size_t)2 * d->desc.Hp * (d->desc.Fp + d->desc.Hp);   // images of W1, W2, W2^T, W1^T
-    SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * wT_f));
-    SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * wT_f, ctx->stream));
+    SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * 2 * wT_f));   // two sets: k_disc_step4 double-buffers them by step parity
+    SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * 2 * wT_f, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_v, 0, sizeof(float) * tot, ctx->stream));
@@ -295,13 +304,50 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipMemcpyAsync(d->d_state, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     sg_ctx_learner_born(ctx);
+#if SG_STEP4_VERIFY
+    SG_CHECK(hipMalloc((void**)&d->d_dbg_step4, sizeof(long long) * 8 * 512 + sizeof(float) * 128 * 8 * 32 * 64 + 4 * 96 * 8 * 8 * 64 + 8 * 4 * 512));
+    SG_CHECK(hipMemset(d->d_dbg_step4, 0, sizeof(long long) * 8 * 512 + sizeof(float) * 128 * 8 * 32 * 64 + 4 * 96 * 8 * 8 * 64 + 8 * 4 * 512));
+#endif
     *out = d;
     return 0;
 }
 
+#if SG_STEP4_VERIFY
+// debug builds only (not in include/simgan_hip.h): the operand words the tile workgroups of the last step consumed
+extern "C" SG_API int sg_debug_step4_log(sg_disc* d, float* out, long long n_floats) {
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    SG_CHECK(hipMemcpy(out, reinterpret_cast<float*>(d->d_dbg_step4 + 8 * 512), sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" SG_API int sg_debug_step4_stamps(sg_disc* d, long long* out) {   // [512][4]
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    SG_CHECK(hipMemcpy(out, reinterpret_cast<unsigned*>(reinterpret_cast<float*>(d->d_dbg_step4 + 8 * 512) + (size_t)128 * 8 * 32 * 64) + 96 * 8 * 8 * 64, 8 * 4 * 512, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" SG_API int sg_debug_step4_chainlog(sg_disc* d, unsigned* out) {   // [96][8][8][64]
+    SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    SG_CHECK(hipMemcpy(out, reinterpret_cast<float*>(d->d_dbg_step4 + 8 * 512) + (size_t)128 * 8 * 32 * 64, 4 * 96 * 8 * 8 * 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 extern "C" int sg_disc_destroy(sg_disc* d) {
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
+#if SG_STEP4_VERIFY
+    if (d->d_dbg_step4) {
+        std::vector<long long> h(8 * 512);
+        (void)hipMemcpy(h.data(), d->d_dbg_step4, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[step4 verify] %lld operand words differed on re-read (steps so far %lld)\n", h[0], (long long)d->opt_t);
+        for (long long i = 0; i < h[0] && i < 100; ++i) {
+            const long long* o = h.data() + 8 + 4 * i;
+            fprintf(stderr, "  block %lld wave %lld lane %lld half %lld cc %lld s %lld side %lld: consumed %08llx re-read %08llx step %lld off %lld\n",
+                    o[0] >> 32, (o[0] >> 16) & 0xffff, (o[0] >> 8) & 0xff, (o[0] >> 4) & 1, (o[0] >> 3) & 1, (o[0] >> 1) & 3, o[0] & 1,
+                    (unsigned long long)o[1] >> 32, (unsigned long long)o[1] & 0xffffffffull, o[2], o[3]);
+        }
+        (void)hipFree(d->d_dbg_step4);
+        d->d_dbg_step4 = nullptr;
+    }
+#endif
     sg_ctx_learner_gone(d->ctx);
     float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT, d->d_erows, d->d_prows};
     for (float* q : ptrs) if (q) (void)hipFree(q);
@@ -547,7 +593,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const bool thin = disc_chain_thin(ctx, dd);
     const bool gw = disc_needs_gw(ctx, dd);
     const int n_chain_wg = thin ? 12 * G : 2 * G;
-    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
+    // (two sets of partials: k_disc_step4 double-buffers them by step parity like the stacks; the two-launch forms use the first)
+    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)2 * 12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
@@ -628,6 +675,11 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
                 pg.erows = d->d_erows; pg.prows = d->d_prows; pg.alpha = a.alpha; pg.ops = a.ops;
                 hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
+#if SG_STEP4_POISON
+                // k_disc_step4's hand-off: the words this step's chain workgroups will write start out poisoned (every later
+                // step's are poisoned by the launch before it)
+                if (fused) hipLaunchKernelGGL(k_disc_poison, dim3(96), dim3(512), 0, ctx->stream, a.ops, a.part, G, dd.Hp, dd.Fp, dd.ldF);
+#endif
             }
             pg.B = k + 1 < n_d ? step_cnt[k + 1] : 0;
             pg.erows = d->d_erows + (size_t)step_off[k + 1] * dd.F; pg.prows = d->d_prows + (size_t)step_off[k + 1] * dd.F;
@@ -636,7 +688,9 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             wa.next = pg;
             if (fused) {
                 Step4Args sa;
-                sa.next = pg; sa.loss_acc = d->d_loss_acc; sa.dbg = d->d_dbg_step4;
+                sa.next = pg; sa.loss_acc = d->d_loss_acc;
+                sa.dbg = (SG_STEP4_VERIFY || k == n_d - 2 || n_d < 2) ? d->d_dbg_step4 : nullptr;   // stamps: one representative step
+                sg_step4_poll_times(dd, &sa.poll_a, &sa.poll_b);
                 launch_disc_step4(ctx, dd, d, a.ops, a.B, G, wa.k1, sa);
                 continue;
             }
@@ -651,6 +705,13 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                                    dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT, wa.k1);
             }
         }
+#if SG_STEP4_POISON
+        if (fused && (n_d & 1)) {   // the last step wrote image set 1: every epoch starts on set 0
+            const int n4 = (2 * dd.Hp * (dd.Fp + dd.Hp)) / 4;
+            hipLaunchKernelGGL(k_disc_img_copy, dim3(48), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(d->d_wT),
+                               reinterpret_cast<const float4*>(d->d_wT + 4 * (size_t)n4), n4);
+        }
+#endif
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, a.st, n_d);
         return 0;
     };

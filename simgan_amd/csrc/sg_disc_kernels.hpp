@@ -443,7 +443,15 @@ struct Chain4Args {
     long long* dbg;
     int B, G;
     float inv_B, lambda_;
+    unsigned* vlog = nullptr;   // SG_STEP4_VERIFY builds: [block][8 waves][8][64 lanes] xor checksums of what the wave computed with
 };
+template <int NW_>
+__device__ __forceinline__ unsigned sg_xor4(const float4 (&w)[NW_]) {
+    unsigned x = 0;
+#pragma unroll
+    for (int t = 0; t < NW_; ++t) x ^= __float_as_uint(w[t].x) ^ (__float_as_uint(w[t].y) * 3u) ^ (__float_as_uint(w[t].z) * 5u) ^ (__float_as_uint(w[t].w) * 7u);
+    return x;
+}
 // A store another workgroup reads.  WT = false: a plain store (the reader is the NEXT launch; the end-of-kernel release
 // writes the line back).  WT = true: a write-through (agent-scope, `sc1`) store for a reader inside the SAME launch
 // (k_disc_step4: the weight-gradient workgroups poll a flag and read with L1-bypassing loads).
@@ -563,6 +571,11 @@ __device__ __forceinline__ void sg_chain4_body(const Chain4Args& a, float* sm) {
             sg_pub<WT>(&L1s[SG_STK(Kt, r0 + s, col)], dz1);
             const float sb = sg4_colsum(dz1);
             if (s == 0) sg_pub<WT>(&part[col], sb);
+            if (a.vlog) {
+                unsigned* o = a.vlog + ((size_t)blockIdx.x * 8 + wave) * 8 * 64 + lane;
+                o[0] = sg_xor4(w1); o[64] = sg_xor4(w2); o[128] = sg_xor4(w2t); o[192] = __float_as_uint(h1); o[256] = __float_as_uint(dz1);
+                o[320] = __float_as_uint(ad[0][0].x) ^ __float_as_uint(ad[0][SG4_NCH(Hp) - 1].y); o[384] = __float_as_uint(h2);
+            }
         }
     } else {
         // ------------------------------------------------ mixup group: gradient penalty on 4 rows
@@ -684,6 +697,11 @@ __device__ __forceinline__ void sg_chain4_body(const Chain4Args& a, float* sm) {
             sg_pub<WT>(&L1s[SG_STK(Kt, rowB + s, col)], z1b);
             const float sb = sg4_colsum(z1b);
             if (s == 0) sg_pub<WT>(&part[col], sb);
+            if (a.vlog) {
+                unsigned* o = a.vlog + ((size_t)blockIdx.x * 8 + wave) * 8 * 64 + lane;
+                o[0] = sg_xor4(w1); o[64] = sg_xor4(w2); o[128] = sg_xor4(w2t); o[192] = __float_as_uint(h1); o[256] = __float_as_uint(z1b);
+                o[320] = sg_xor4(w1t); o[384] = __float_as_uint(h2); o[448] = __float_as_uint(u1);
+            }
         }
     }
     SG_PHASE_SYNC(31);

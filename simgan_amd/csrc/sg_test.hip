@@ -554,16 +554,16 @@ extern "C" int sg_test_disc_phase_times(sg_disc* d, int enable, long long* out, 
 }
 
 // Test hook: per-phase shader-clock timestamps of k_ppo_fwd, row groups [0, n_blocks) (tools/ppo_phase_times.py).
-// k_disc_step4's wall-clock stamps (library built with -DSG_STEP4_STAMPS=1): 8 per workgroup, of the epoch's last step
+// k_disc_step4's wall-clock stamps (library built with -DSG_STEP4_STAMPS=1): 16 per workgroup, of the epoch's last-but-one step (the last has no next step's rows to copy)
 extern "C" int sg_test_disc_step4_times(sg_disc* d, int enable, long long* out, int n_blocks) {
     SG_REQUIRE(d && n_blocks >= 0 && n_blocks <= 512, "sg_test_disc_step4_times: bad argument");
     SG_CHECK(hipSetDevice(d->ctx->device));
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
     if (enable && !d->d_dbg_step4) {
-        SG_CHECK(hipMalloc((void**)&d->d_dbg_step4, sizeof(long long) * 8 * 512));
-        SG_CHECK(hipMemset(d->d_dbg_step4, 0, sizeof(long long) * 8 * 512));
+        SG_CHECK(hipMalloc((void**)&d->d_dbg_step4, sizeof(long long) * 16 * 512));
+        SG_CHECK(hipMemset(d->d_dbg_step4, 0, sizeof(long long) * 16 * 512));
     }
-    if (out && d->d_dbg_step4) SG_CHECK(hipMemcpy(out, d->d_dbg_step4, sizeof(long long) * 8 * n_blocks, hipMemcpyDeviceToHost));
+    if (out && d->d_dbg_step4) SG_CHECK(hipMemcpy(out, d->d_dbg_step4, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost));
     if (!enable && d->d_dbg_step4) { SG_CHECK(hipFree(d->d_dbg_step4)); d->d_dbg_step4 = nullptr; }
     return 0;
 }

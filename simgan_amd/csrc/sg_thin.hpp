@@ -39,9 +39,19 @@ __host__ __device__ __forceinline__ int sg4_img_index(int n, int k, int K) {
 // This lane's B operand for the whole kernel: wave-th 16-column slice of an image.
 template <int K>
 __device__ __forceinline__ void sg4_load_w(float4 (&w)[SG4_NW(K)], const float* img, int wave, int lane) {
+#if defined(SG4_W_SC1) && SG4_W_SC1   // diagnostic builds: the weight slices past the CU's L1 (and, with sc1, past stale L2 copies)
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < SG4_NW(K); ++t) {
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((((size_t)wave * SG4_NW(K) + t) * 64 + lane) * 16), 0, 16);
+        w[t] = float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+#else
     const float4* p = reinterpret_cast<const float4*>(img) + (size_t)wave * SG4_NW(K) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < SG4_NW(K); ++t) w[t] = p[t * 64];
+#endif
 }
 
 // A operand of RG row groups from X (LDS or global, leading dimension ldx, 16-byte aligned rows).

@@ -23,20 +23,39 @@ disc.update_gail_dyn(loader, ro)
 G = (w["B"] + 15) // 16
 kf, kh = (w["F"] + 15) // 16, (w["Hd"] + 15) // 16
 nc, wb = 12 * G, (12 * G + 7) & ~7
-n = wb + 8 * (kf + kh)
-buf = (C.c_longlong * (8 * 512))()
+n = wb + 8 * (kf + kh) + 2 * G
+S = 16   # stamp slots per workgroup (SG_STEP4_STAMP_SLOTS)
+buf = (C.c_longlong * (S * 512))()
 _lib.check_test(fn(disc.h, 1, buf, 512))
-t = np.array(buf, dtype=np.int64).reshape(512, 8)[:n, :4] * 10  # ns
+raw = np.array(buf, dtype=np.int64).reshape(512, S)[:n]
+t = raw * 10  # ns
 c = t[:nc]
 t0 = c[:, 0].min()
+
+
+def rng(x):
+    x = x[x > 0]
+    return f"{x.min() - t0}..{x.max() - t0} (median {int(np.median(x)) - t0})" if len(x) else "-"
+
+
 mix, bce = c[:4 * G], c[4 * G:]
-for nm, x in (("mixup chain blocks", mix), ("BCE chain blocks", bce)):
-    print(f"{nm}: start {x[:, 0].min() - t0}..{x[:, 0].max() - t0} ns, body done {x[:, 1].min() - t0}..{x[:, 1].max() - t0}, "
-          f"stores drained {x[:, 2].min() - t0}..{x[:, 2].max() - t0}, flag stored {x[:, 3].min() - t0}..{x[:, 3].max() - t0}")
-wt = t[wb:]
-wt = wt[wt[:, 0] > 0]
-print(f"tile blocks ({len(wt)}): ready to wait {wt[:, 0].min() - t0}..{wt[:, 0].max() - t0} ns, flags seen {wt[:, 1].min() - t0}..{wt[:, 1].max() - t0} "
-      f"(median {int(np.median(wt[:, 1])) - t0}), operands in + MFMA {wt[:, 2].min() - t0}..{wt[:, 2].max() - t0} (median {int(np.median(wt[:, 2])) - t0}), "
-      f"LDS reduce barrier {wt[:, 3].min() - t0}..{wt[:, 3].max() - t0}")
-print(f"last flag stored -> median tile block saw the flags: {int(np.median(wt[:, 1])) - c[:, 3].max()} ns; -> operands in {int(np.median(wt[:, 2])) - c[:, 3].max()} ns")
+print(f"mixup chain blocks: start {rng(mix[:, 0])}, body done {rng(mix[:, 1])}; flag form: stores drained {rng(mix[:, 2])}, flag stored {rng(mix[:, 3])}")
+print(f"BCE chain blocks:   start {rng(bce[:, 0])}, body done {rng(bce[:, 1])}; flag form: stores drained {rng(bce[:, 2])}, flag stored {rng(bce[:, 3])}")
+ntv = 8 * (kf + kh)
+xcd = np.arange(ntv) & 7
+tt = t[wb + np.nonzero(xcd < kh)[0]]
+vt = t[wb + np.nonzero(xcd >= kh)[0]]
+vt = vt[vt[:, 0] > 0]
+gt = t[wb + ntv:]
+gt = gt[gt[:, 0] > 0]
+if len(vt):
+    print(f"vector blocks ({len(vt)}): start {rng(vt[:, 0])}, partials in {rng(vt[:, 1])}, reduce barrier {rng(vt[:, 2])}, stores acknowledged {rng(vt[:, 3])}")
+if len(gt):
+    print(f"row-copy blocks ({len(gt)}): start {rng(gt[:, 0])}, stores acknowledged {rng(gt[:, 1])}")
+rounds = raw[wb + np.nonzero(xcd < kh)[0]][:, 7]
+print(f"tile blocks ({len(tt)}), wave 0: ready {rng(tt[:, 0])}")
+print(f"  BCE half:   requested {rng(tt[:, 1])}, first answer {rng(tt[:, 2])}, contracted {rng(tt[:, 3])}, re-request rounds {np.bincount(rounds & 0xffff)}")
+print(f"  mixup half: requested {rng(tt[:, 4])}, first answer {rng(tt[:, 5])}, contracted {rng(tt[:, 6])}, re-request rounds {np.bincount(rounds >> 16)}")
+print(f"  past the reduce barrier {rng(tt[:, 8])}, Adam done and stores acknowledged {rng(tt[:, 9])}")
+print(f"last chain body done -> median tile wave 0 has its operands contracted: {int(np.median(tt[:, 6])) - c[:, 1].max()} ns; -> last tile block's stores acknowledged: {tt[:, 9].max() - c[:, 1].max()} ns")
 _lib.check_test(fn(disc.h, 0, None, 0))
