@@ -245,6 +245,208 @@ def cpu_baseline(w, expert, budget_s):
     return out
 
 
+PROF_SLOTS = ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam", "disc_step"]
+
+
+def load_tdoc(workload):
+    """The committed counter / kernel-trace summary of `workload` (tools/profile_workload.sh -> tools/make_traffic.py ->
+    profiles/traffic.json), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)["workloads"].get(workload, {})
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def kernel_report(w, work, prof, tdoc):
+    """Per-kernel roofline entries from the HIP-event pass `prof` (slot -> (total ms, launches)) and the dominant kernel:
+    the discriminator step -- one launch (k_disc_step4) where the library runs it so, else its chain kernel -- or, without
+    a discriminator, the PPO backward."""
+    def tk(kname, key):
+        try:
+            return tdoc["kernels"][kname][key]
+        except KeyError:
+            return None
+
+    kmap = {}
+    for slot, (kname, bound, kflops, kbytes) in work["kernels"].items():
+        ms_, n_ = prof[slot]
+        if not n_:
+            continue
+        avg_s = ms_ / n_ * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = kflops / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = kbytes / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        pus = tk(kname, "rocprof_avg_us")
+        kmap[kname] = {"bound": bound, "avg_us": round(avg_s * 1e6, 2), "launches": n_, "algorithmic_flops": kflops,
+                       "algorithmic_bytes": kbytes, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
+                       "rocprof_avg_us": pus, "frac_profiled": round(ach / peak * (avg_s * 1e6) / pus, 5) if pus else None,
+                       "traffic": tk(kname, "hbm_bytes_per_launch")}
+    one_launch = bool(w["E_d"]) and prof["disc_step"][1] > 0
+    slot = ("disc_step" if one_launch else "disc_chain") if w["E_d"] else "ppo_bwd"
+    kname = work["kernels"][slot][0]
+    flops = (work["d_step_flops"] if one_launch else work["d_chain_flops"]) if w["E_d"] else work["ppo_step_flops"]
+    ms_, n_ = prof[slot]
+    avg_s = (ms_ / max(n_, 1)) * 1e-3
+    achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+    pus = tk(kname, "rocprof_avg_us")
+    dom = {"kernel": kname, "flops": flops, "avg_s": avg_s, "launches": n_, "achieved": achieved,
+           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "rocprof_avg_us": pus,
+           "frac_profiled": (flops / (pus * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if pus else None,
+           "traffic": tk(kname, "hbm_bytes_per_launch")}
+    return kmap, dom
+
+
+def spread_of(ms):
+    ms = sorted(ms)
+    return {"min_ms": round(ms[0], 3), "median_ms": round(ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]), 3),
+            "max_ms": round(ms[-1], 3), "n": len(ms), "clock": "one HIP event between consecutive updates on the library's stream (sg_ctx_mark), read after the loop"}
+
+
+def run_updates(ctx, learner, steps):
+    """`steps` updates back to back with a device timestamp between them -> (wall seconds incl. the final synchronise,
+    per-update milliseconds on the device's clock, the last update's losses)."""
+    ctx.marks_reset()
+    marks = [ctx.mark()]
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = learner.update()
+        marks.append(ctx.mark())
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    per = [ctx.mark_elapsed(marks[i], marks[i + 1]) for i in range(steps)]
+    ctx.marks_reset()
+    return wall, per, last
+
+
+def profile_pass(ctx, learner):
+    """Per-kernel durations with HIP events on the library's stream (separate, untimed update)."""
+    ctx.profile_reset()
+    ctx.profile(True)
+    learner.update()
+    ctx.profile(False)
+    return {name: ctx.profile_read(i) for i, name in enumerate(PROF_SLOTS)}
+
+
+def brief_workload(sg, _lib, ctx, name, steps=10, warmup=5):
+    """One of BASELINE.json's other configurations, timed like the headline but briefly (device-resident rollout, `warmup`
+    untimed + `steps` timed updates, one HIP-event pass) -- so that the driver's own bench run carries a number for every
+    configuration BASELINE.json names, not only the one `value` is quoted on."""
+    w = WORKLOADS[name]
+    pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, seed=0)
+    _lib.check(ctx.lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
+    for _ in range(warmup):
+        learner.update()
+    ctx.synchronize()
+    wall, per, last = run_updates(ctx, learner, steps)
+    prof = profile_pass(ctx, learner)
+    work = algorithmic_work(w, 1)
+    kmap, dom = kernel_report(w, work, prof, load_tdoc(name))
+    ms = 1e3 * wall / steps
+    out = {"metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else "env-steps/sec of PPO update (a2c/main.py)",
+           "value": round(w["T"] * w["N"] * steps / wall, 1), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "spread": spread_of(per), "optimizer_steps_per_update": work["d_steps"] + work["ppo_steps"],
+           "us_per_optimizer_step": round(1e3 * ms / (work["d_steps"] + work["ppo_steps"]), 2),
+           "shape": f"T={w['T']} N={w['N']} obs={w['O']} act={w['A']} D-in={w['F'] if w['E_d'] else '-'} policy={w['kind']} h{w['H']} num_mini_batch={w['M']}",
+           "roofline": {"kernel": dom["kernel"], "bound": "mfma", "avg_launch_us": round(dom["avg_s"] * 1e6, 2), "launches": dom["launches"],
+                        "achieved": round(dom["achieved"], 3), "unit": "TFLOP/s", "frac": round(dom["frac"], 5),
+                        "frac_profiled": round(dom["frac_profiled"], 5) if dom["frac_profiled"] else None},
+           "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items() if v[1]},
+           "last_losses": dict(last)}
+    del learner, agent, disc, ro, pol, loader, last
+    import gc
+    gc.collect()
+    return out
+
+
+def dropin_leg(sg, _lib, ctx, w, updates=5):
+    """What a user of the reference's UNCHANGED main pays (never `value`): the rollout handed over as HOST tensors, every
+    call of a2c/main_gail_dyn_ppo.py:255-304 made literally through the alias classes of third_party/a2c_ppo_acktr/ --
+    gail_epoch x update_gail_dyn (losses read back), T x [predict_reward_combined + host ret_rms.update + clip],
+    compute_returns, agent.update, after_update -- plus, beside it, the same update through GailDynLearner on host buffers
+    (fused on-device relabel instead of the T-step loop) and the bare upload of one whole rollout."""
+    import torch
+    from third_party.a2c_ppo_acktr import algo                      # the names the main imports (:30-38)
+    from third_party.a2c_ppo_acktr.storage import RolloutStorage    # noqa: F401  (build_problem constructs the same class)
+    from simgan_amd.driver import alive_bonus_offset
+    from simgan_amd.utils import RunningMeanStd
+    assert algo.PPO is sg.algo.PPO and RolloutStorage is sg.RolloutStorage
+    torch.set_num_threads(1)     # a2c/main_gail_dyn_ppo.py:64 (with a thread per core of a 100+-core host, torch's pool turns every
+    T, N = w["T"], w["N"]        # small host-side tensor op of the sequence into a 10-50 ms stall: measured, DESIGN.md section 5)
+    res = {"updates_timed": updates, "note": "host tensors in, host tensors out; PCIe and every read-back included; not the metric's `value`"}
+
+    def fresh():
+        pol, disc, agent, ro, loader, expert, learner = build_problem(sg, w, seed=0)
+        _lib.check(ctx.lib.sg_rollout_fill_synthetic(ro.h, pol.h, 1234, 0.01))
+        ro.sync_from_device()            # the host tensors now hold the synthetic rollout
+        ro.device_resident = False
+        return pol, disc, agent, ro, loader, learner
+
+    def refill(ro):                      # what the next rollout's insert() calls mean for the device copy: every field is new
+        ro.mark_host_written()
+
+    # (1) the literal main
+    pol, disc, agent, ro, loader, learner = fresh()
+    ret_rms = RunningMeanStd(shape=())
+
+    def main_iteration():
+        with torch.no_grad():
+            next_value = pol.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()
+        for _ in range(w["E_d"]):
+            gail_loss, gail_loss_e, gail_loss_p = disc.update_gail_dyn(loader, ro)
+        num_of_dones = float((1.0 - ro.masks).sum().cpu().numpy())
+        r_sa = alive_bonus_offset(num_of_dones, T, N, 500.0)
+        for step in range(T):
+            ro.rewards[step], returns = disc.predict_reward_combined(ro.obs_feat[step + 1], GAMMA, ro.masks[step], offset=-r_sa)
+            ret_rms.update(returns.view(-1).cpu().numpy())
+            rews = ro.rewards[step].view(-1).cpu().numpy()
+            rews = np.clip(rews / np.sqrt(ret_rms.var + 1e-7), -10.0, 10.0)
+            ro.rewards[step] = torch.Tensor(rews).view(-1, 1)
+        ro.compute_returns(next_value, True, GAMMA, LAM, True)
+        out = agent.update(ro)
+        ro.after_update()
+        return out
+
+    def timed_host(fn):
+        fn()
+        fn()
+        ctx.synchronize()
+        per, b0 = [], ro.bytes_uploaded
+        for _ in range(updates):
+            t0 = time.perf_counter()
+            refill(ro)
+            fn()
+            ctx.synchronize()
+            per.append(1e3 * (time.perf_counter() - t0))
+        return sum(per) / len(per) * 1e-3, per, (ro.bytes_uploaded - b0) // updates
+
+    dt, per, up = timed_host(main_iteration)
+    res["literal_main"] = {"ms_per_step": round(1e3 * dt, 3), "env_steps_s": round(T * N / dt, 1), "min_ms": round(min(per), 3), "max_ms": round(max(per), 3),
+                           "bytes_uploaded_per_update": up,
+                           "sequence": f"{w['E_d']} x update_gail_dyn, {T} x (predict_reward_combined + ret_rms.update + clip), compute_returns, agent.update, after_update"}
+    # the bare upload of one rollout (every field once)
+    ctx.synchronize()
+    b1, t0 = ro.bytes_uploaded, time.perf_counter()
+    for _ in range(3):
+        ro.sync_to_device()
+    ctx.synchronize()
+    res["rollout_upload_ms"] = round(1e3 * (time.perf_counter() - t0) / 3, 3)
+    res["rollout_bytes"] = (ro.bytes_uploaded - b1) // 3
+    del learner, agent, disc, ro, pol, loader
+    import gc
+    gc.collect()
+    # (2) GailDynLearner.update() on host buffers
+    pol, disc, agent, ro, loader, learner = fresh()
+    dt, per, up = timed_host(learner.update)
+    res["learner_host_buffers"] = {"ms_per_step": round(1e3 * dt, 3), "env_steps_s": round(T * N / dt, 1), "min_ms": round(min(per), 3),
+                                   "max_ms": round(max(per), 3), "bytes_uploaded_per_update": up}
+    del learner, agent, disc, ro, pol, loader
+    gc.collect()
+    return res
+
+
 class Watchdog(object):
     """First-run insurance for the N-GPU launch: whatever happens -- a hung ncclCommInitRank, a first collective that never
     completes, a peer that dies and takes the launcher's SIGTERM with it -- rank 0 still prints ONE JSON line, carrying
@@ -261,6 +463,7 @@ class Watchdog(object):
         os.makedirs(self.dir, exist_ok=True)
         self.lock = threading.Lock()
         self.name, self.deadline, self.done = "start", time.time() + 600.0, False
+        self.final = None        # set once the headline line is complete (legs reported beside it may still fail)
         self.t0 = time.time()
         self._write()
         # a SIGTERM (torch.distributed.run ends the surviving ranks when one rank fails) must not lose the line either: the
@@ -311,6 +514,12 @@ class Watchdog(object):
             stage = self.name
         self._write()
         sys.stderr.write(f"[bench] rank {self.rank}: {why} in stage '{stage}'\n")
+        if self.rank == 0 and self.final is not None:
+            # the headline measurement is complete and only a leg reported beside it went wrong: the line goes out as it stands
+            line = dict(self.final)
+            line.update({"error_after_headline": why, "stage": stage, "elapsed_s": round(time.time() - self.t0, 1)})
+            self.emit(line)
+            os._exit(0)
         if self.rank == 0:
             time.sleep(1.0)      # let the other ranks' watchdogs record their final stage
             line = dict(self.base)
@@ -366,6 +575,9 @@ def main():
     ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the brief runs of BASELINE.json's other configurations")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (the unchanged main's call sequence on host tensors)")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline measurement (+ cpu baseline unless --no-cpu-baseline)")
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
     ap.add_argument("--init-timeout", type=float, default=480.0, help="watchdog budget (s) for start-up: imports, context, communicator, problem build")
     ap.add_argument("--stage-timeout", type=float, default=420.0, help="watchdog budget (s) for each later stage (warm-up, timed region, profile pass, ...)")
@@ -459,41 +671,24 @@ def main():
             if not replica["ok"]:
                 dog.fail(f"replicas diverged after the warm-up: weight hashes per rank {[d[:12] for d in digests]}", code=4)
         dog.stage(f"{label}timed region ({steps} updates)", args.stage_timeout)
-        t0 = time.perf_counter()
-        last_ = None
-        for _ in range(steps):
-            last_ = learner.update()
-        ctx.synchronize()
-        mine = time.perf_counter() - t0
+        mine, per_update, last_ = run_updates(ctx, learner, steps)
         barrier()
+        spreads.append(per_update)
         return pg.max(mine), pg.gather(mine), last_
 
+    spreads = []
     elapsed, per_rank, last = timed(args.steps, args.warmup)
     # self-test of the N > 1 reporting path on one GPU (with SG_COMM_ALWAYS=1 the collectives stay in the launch sequence)
     force_alt = world == 1 and os.environ.get("SG_BENCH_FORCE_ALT") == "1" and ctx.comm_info()[1] == 1 and os.environ.get("SG_COMM_ALWAYS") == "1"
     # per-kernel durations with HIP events on the library's stream (separate, untimed pass)
     dog.stage("per-kernel HIP-event pass", args.stage_timeout)
-    ctx.profile_reset()
-    ctx.profile(True)
-    learner.update()
-    ctx.profile(False)
-    prof = {name: ctx.profile_read(i) for i, name in enumerate(
-        ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam", "disc_step"])}
+    prof = profile_pass(ctx, learner)
 
     if rank == 0:
         work = algorithmic_work(w, world, ctx.disc_sharded)
         env_steps = w["T"] * w["N"] * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = env_steps * args.steps / elapsed
-        # the kernel most of the update's time goes to: the discriminator step -- one launch (k_disc_step4) where the library
-        # runs it so, else its chain kernel -- or, without a discriminator, the PPO backward
-        one_launch = bool(w["E_d"]) and prof["disc_step"][1] > 0
-        dom = ("disc_step" if one_launch else "disc_chain") if w["E_d"] else "ppo_bwd"
-        dom_kernel = ("k_disc_step4" if one_launch else "k_disc_chain4") if w["E_d"] else "k_ppo_bwd"
-        dom_flops = (work["d_step_flops"] if one_launch else work["d_chain_flops"]) if w["E_d"] else work["ppo_step_flops"]
-        dg_ms, dg_n = prof[dom]
-        dg_avg_s = (dg_ms / max(dg_n, 1)) * 1e-3
-        achieved = dom_flops / dg_avg_s / 1e12 if dg_avg_s > 0 else 0.0
         name, num_cu, hbm = ctx.device_info()
         # PMC passes and rocprofv3's kernel trace cannot run inside the timed process: counter traffic and the profiler's
         # own per-kernel durations come from the committed summary of the last profile run of THIS workload
@@ -502,20 +697,11 @@ def main():
         import hashlib
         with open(_lib.LIB_PATH, "rb") as f:
             lib_sha = hashlib.sha256(f.read()).hexdigest()
-        tdoc = {}
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
-                tdoc = json.load(f)["workloads"].get(args.workload, {})
-        except (OSError, KeyError, ValueError):
-            tdoc = {}
+        tdoc = load_tdoc(args.workload)
         traffic_sha = tdoc.get("lib_sha256")
         traffic_stale = bool(tdoc) and traffic_sha != lib_sha
-
-        def counter_traffic(kname):
-            try:
-                return tdoc["kernels"][kname]["hbm_bytes_per_launch"]
-            except KeyError:
-                return None
+        kmap, dom = kernel_report(w, work, prof, tdoc)
+        dom_kernel, dom_flops, dg_avg_s, dg_n, achieved, traffic = dom["kernel"], dom["flops"], dom["avg_s"], dom["launches"], dom["achieved"], dom["traffic"]
 
         def profiled_us(kname):
             try:
@@ -523,25 +709,10 @@ def main():
             except KeyError:
                 return None
 
-        traffic = counter_traffic(dom_kernel)
-        kmap = {}
-        for slot, (kname, bound, kflops, kbytes) in work["kernels"].items():
-            ms_, n_ = prof[slot]
-            if not n_:
-                continue
-            avg_s = ms_ / n_ * 1e-3
-            if bound == "mfma":
-                ach, peak, unit = kflops / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
-            else:
-                ach, peak, unit = kbytes / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
-            pus = profiled_us(kname)
-            kmap[kname] = {"bound": bound, "avg_us": round(avg_s * 1e6, 2), "launches": n_, "algorithmic_flops": kflops,
-                           "algorithmic_bytes": kbytes, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
-                           "rocprof_avg_us": pus, "frac_profiled": round(ach / peak * (avg_s * 1e6) / pus, 5) if pus else None,
-                           "traffic": counter_traffic(kname)}
         out = {
             "metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else ("env-steps/sec of PPO update (policy refinement, a2c/main.py)" if args.workload == "refine" else "env-steps/sec of PPO update (a2c/main.py)"), "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "spread": spread_of(spreads[0]),     # this rank's device clock, update by update, over the timed region
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.workload}: GAIL-dyn update, T={w['T']} N={w['N']}/GPU obs={w['O']} act={w['A']} "
                                     f"D-in={w['F']} policy={w['kind']} h{w['H']} D h{w['Hd']} ppo_epoch={w['E_p']} "
@@ -625,6 +796,28 @@ def main():
         ctx.set_disc_dp(not ctx.disc_sharded)
         if rank == 0:
             out["comm"]["disc_other_mode"] = alt
+    if world == 1 and not force_alt and not args.headline_only:
+        # Everything below is reported BESIDE `value`, never as it; the headline is complete.  A leg that fails or runs out
+        # of its budget leaves an `error` entry: the line is not lost (the stage watchdog prints what it has and ends the run).
+        dog.final = out
+        import gc
+        del learner, agent, disc, ro, pol, loader
+        gc.collect()    # the handles are freed HERE (hipFree waits for the device), not by a collection inside a later timed loop
+        if args.workload == "northstar" and not args.no_other_workloads:
+            out["other_workloads"] = {}
+            for other_name in ("hopper", "laikago", "refine", "hopper_ppo"):   # BASELINE.json configs[1], [2], [4], [0]
+                dog.stage(f"other workload: {other_name}", 120.0)
+                try:
+                    out["other_workloads"][other_name] = brief_workload(sg, _lib, ctx, other_name)
+                except Exception as exc:
+                    out["other_workloads"][other_name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if w["E_d"] and not args.no_dropin:
+            dog.stage("drop-in legs (host tensors through the alias classes)", 180.0)
+            try:
+                out["dropin"] = dropin_leg(sg, _lib, ctx, w)
+            except Exception as exc:
+                out["dropin"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        dog.stage("cpu baseline / output", 1e9)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, expert, args.cpu_seconds)

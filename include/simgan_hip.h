@@ -257,6 +257,13 @@ SG_API int sg_disc_get_scalars(sg_disc *d, double out5[5]);
 /* sum(1 - masks) over all T+1 slots (a2c/main_gail_dyn_ppo.py:258), for the alive-bonus offset. */
 SG_API int sg_rollout_count_dones(sg_rollout *r, double *dones);
 
+/* Page-locked host memory for buffers that cross the boundary every update (the rollout's host tensors: a2c/storage.py:37-53
+ * allocates them with torch.zeros and `.to(device)` moves them, :57-68; here they stay on the host and sg_rollout_upload /
+ * _download move their content).  From such memory a field crosses PCIe as one DMA at the link's speed; from pageable
+ * memory the same calls work, through the runtime's staging path.  No context needed. */
+SG_API int sg_host_alloc(int64_t bytes, void **out);
+SG_API int sg_host_free(void *p);
+
 /* ------------------------------------------------------------- measurement */
 /* HIP-event timing of the dominant kernels on the library's stream since the last reset:
  * which = 0 k_disc_chain (discriminator step, serial part), 1 k_disc_wgrad (weight gradients + Adam),
@@ -266,6 +273,13 @@ SG_API int sg_rollout_count_dones(sg_rollout *r, double *dones);
 SG_API int sg_ctx_profile(sg_ctx *ctx, int enable);
 SG_API int sg_ctx_profile_read(sg_ctx *ctx, int which, double *total_ms, int64_t *launches);
 SG_API int sg_ctx_profile_reset(sg_ctx *ctx);
+/* A timestamp on the library's stream, taken by the device when it gets there (one HIP event; the host does not wait):
+ * *id = the mark's number.  bench.py brackets every timed update with one and reads the per-update spread after the loop --
+ * the reference times its updates with time.time() around the same calls (a2c/main_gail_dyn_ppo.py:318-321).
+ * id = NULL: synchronise and forget every mark. */
+SG_API int sg_ctx_mark(sg_ctx *ctx, int *id);
+/* Milliseconds between two marks (waits for mark `to`). */
+SG_API int sg_ctx_mark_elapsed(sg_ctx *ctx, int from, int to, double *ms);
 
 #ifdef __cplusplus
 }

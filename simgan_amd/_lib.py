@@ -103,6 +103,10 @@ PROTOTYPES = {
     "sg_ctx_profile": (C.c_int, [H, C.c_int]),
     "sg_ctx_profile_read": (C.c_int, [H, C.c_int, c_double_p, c_i64_p]),
     "sg_ctx_profile_reset": (C.c_int, [H]),
+    "sg_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "sg_host_free": (C.c_int, [C.c_void_p]),
+    "sg_ctx_mark": (C.c_int, [H, c_int_p]),
+    "sg_ctx_mark_elapsed": (C.c_int, [H, C.c_int, C.c_int, c_double_p]),
 }
 
 # libsimgan_hip_test.so (csrc/sg_test_api.h): test hooks and probes, for tests/ and tools/ only
@@ -204,6 +208,38 @@ def as_i64(x):
     return np.ascontiguousarray(x, dtype=np.int64)
 
 
+class _PinnedBlock(object):
+    """One sg_host_alloc allocation, freed when the last array viewing it is gone."""
+
+    def __init__(self, nbytes):
+        self.lib = load()
+        p = C.c_void_p()
+        check(self.lib.sg_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.sg_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_array(shape, fill=0.0):
+    """float32 numpy array of `shape` in page-locked host memory (include/simgan_hip.h: sg_host_alloc).  The allocation
+    lives as long as any view of the array (numpy / torch.from_numpy keep the owner alive through `.base`)."""
+    n = int(np.prod(shape)) * 4
+    if n == 0:
+        return np.full(shape, fill, np.float32)
+    blk = _PinnedBlock(n)
+    buf = (C.c_char * n).from_address(blk.ptr)
+    buf._owner = blk
+    a = np.frombuffer(buf, dtype=np.float32).reshape(shape)
+    a[...] = fill
+    return a
+
+
 _CTX = {}
 
 
@@ -275,6 +311,20 @@ class Context:
     def set_disc_dp(self, sharded):
         check(self.lib.sg_ctx_set_disc_dp(self.h, 1 if sharded else 0))
         self.disc_sharded = bool(sharded)
+
+    def mark(self):
+        """A timestamp on the library's stream (the host does not wait) -> its number."""
+        i = C.c_int(0)
+        check(self.lib.sg_ctx_mark(self.h, C.byref(i)))
+        return i.value
+
+    def mark_elapsed(self, a, b):
+        ms = C.c_double(0)
+        check(self.lib.sg_ctx_mark_elapsed(self.h, a, b, C.byref(ms)))
+        return ms.value
+
+    def marks_reset(self):
+        check(self.lib.sg_ctx_mark(self.h, None))
 
     def profile(self, enable):
         check(self.lib.sg_ctx_profile(self.h, 1 if enable else 0))

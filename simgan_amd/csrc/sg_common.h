@@ -109,6 +109,7 @@ struct sg_ctx {
     bool profile = false;
     SgProfSlot prof[SG_PROF_COUNT];
     std::vector<hipEvent_t> event_pool;
+    std::vector<hipEvent_t> marks;   // sg_ctx_mark: timestamps on the stream between updates (bench.py's per-update spread)
     SgComm* comm = nullptr;
     int rank = 0, world = 1;
     bool disc_sharded = false;    // SG_DISC_DP=sharded: all-reduce D gradients per step instead of replicating D

@@ -176,7 +176,7 @@ class GailDynLearner(object):
             last = e == self.gail_epoch - 1
             gail = self.discr.update_gail_dyn(self.loader, ro, **({} if last else {"fetch_losses": False}))
         # drop-in mode: the host tensors are the rollout; every call below uploads what it reads and returns its result
-        ro.sync_to_device([_lib.F_MASKS])
+        ro._push([_lib.F_MASKS])
         dones = C.c_double(0)
         _lib.check(lib.sg_rollout_count_dones(ro.h, C.byref(dones)))   # all ranks when world > 1
         r_sa = alive_bonus_offset(dones.value, ro.num_steps, ro.num_processes * self.world, self.gail_tar_length,

@@ -3,12 +3,19 @@
 The reference mains read and write the buffers by slicing (`rollouts.obs[0].copy_(obs)`,
 `rollouts.rewards[step] = ...`), so the attributes stay ordinary host tensors with the
 reference's shapes.  The HBM copy inside libsimgan_hip.so is refreshed per operation:
-  * default (drop-in) mode: every device operation first uploads the fields it reads and
-    downloads the fields it writes -- PCIe-inclusive, always coherent with host-side edits;
+  * default (drop-in) mode: every device operation first uploads the fields it reads -- those whose host tensor
+    changed since the device copy last matched it -- and downloads the fields it writes: PCIe-inclusive, coherent with
+    host-side edits.  "Changed" is read off the tensor itself: every in-place torch operation on the attribute or on
+    a slice of it (`rollouts.rewards[step] = ...`, `rollouts.obs[0].copy_(obs)`, `insert`) bumps its `_version`; an
+    attribute that is re-bound is a different tensor.  So `obs_feat` crosses PCIe once per rollout, not once per
+    discriminator epoch.  Writes torch cannot see (through a `.numpy()` view of the attribute) need
+    `mark_host_written()`; without torch (plain numpy mirrors) and with SG_ROLLOUT_ALWAYS_UPLOAD=1 every call uploads;
   * `device_resident = True` (driver / bench fast path): uploads are skipped, the device copy is
     the source of truth and `sync_from_device()` refreshes the host view on demand.
 """
 import ctypes as C
+import os
+import weakref
 
 import numpy as np
 
@@ -31,8 +38,12 @@ class RolloutStorage(object):
         if len(obs_shape) != 1:
             raise NotImplementedError("1-D observations only")
         O, A, F = int(obs_shape[0]), int(action_space.shape[0]), int(feat_len)
-        z = lambda *s: to_host_tensor(np.zeros(s, np.float32))  # noqa: E731
-        o = lambda *s: to_host_tensor(np.ones(s, np.float32))  # noqa: E731
+        self.ctx = ctx or _lib.Context.default()   # (first: creating the context is what initialises the HIP runtime, with its settings)
+        self.lib = self.ctx.lib
+        # the host tensors live in page-locked memory (sg_host_alloc): ordinary CPU tensors to whoever slices them, one DMA
+        # per field at the link's speed to sg_rollout_upload / _download
+        z = lambda *s: to_host_tensor(_lib.pinned_array(s, 0.0))  # noqa: E731
+        o = lambda *s: to_host_tensor(_lib.pinned_array(s, 1.0))  # noqa: E731
         self.obs = z(T + 1, N, O)
         self.obs_feat = z(T + 1, N, F)
         self.recurrent_hidden_states = z(T + 1, N, recurrent_hidden_state_size)
@@ -48,11 +59,11 @@ class RolloutStorage(object):
         self.num_processes = N
         self.step = 0
         self.obs_dim, self.act_dim, self.feat_len = O, A, F
-        self.device_resident = False
+        self._device_resident = False
         self._host_written = False   # insert() wrote host slots since the last after_update()
+        self._synced = {}            # field -> (weakref of the host tensor, its _version) when the device copy last matched it
+        self.bytes_uploaded = 0      # host -> device traffic of this rollout so far (bench.py's `dropin` leg reads it)
 
-        self.ctx = ctx or _lib.Context.default()
-        self.lib = self.ctx.lib
         h = _lib.H()
         _lib.check(self.lib.sg_rollout_create(self.ctx.h, T, N, O, A, F, C.byref(h)))
         self.h = h
@@ -76,21 +87,55 @@ class RolloutStorage(object):
             raise TypeError(f"rollouts.{_FIELD_ATTR[field]} must stay a contiguous float32 host tensor")
         return a
 
+    @property
+    def device_resident(self):
+        return self._device_resident
+
+    @device_resident.setter
+    def device_resident(self, value):
+        # resident operations change the device copy without telling the host mirrors: nothing is known to match afterwards
+        self._device_resident = bool(value)
+        self._synced = {}
+
+    def _stamp(self, field):
+        """What identifies the present content of a host field: (the tensor, its version counter), or None when writes to
+        it cannot be seen (numpy mirrors)."""
+        t = getattr(self, _FIELD_ATTR[field])
+        v = getattr(t, "_version", None)
+        return None if v is None else (weakref.ref(t), v)
+
+    def _matches(self, field):
+        was, now = self._synced.get(field), self._stamp(field)
+        return was is not None and now is not None and was[0]() is now[0]() and was[1] == now[1]
+
+    def mark_host_written(self, fields=None):
+        """Tell the rollout that host fields were written behind torch's back (through a numpy view)."""
+        for f in (fields if fields is not None else list(self._synced)):
+            self._synced.pop(f, None)
+
     def sync_to_device(self, fields=None):
         for f in (fields if fields is not None else _FIELD_ATTR):
             a = self._host_np(f)
             if a.size:
                 _lib.check(self.lib.sg_rollout_upload(self.h, f, _lib.fptr(a), a.size))
+                self.bytes_uploaded += a.nbytes
+            self._synced[f] = self._stamp(f)
 
     def sync_from_device(self, fields=None):
         for f in (fields if fields is not None else _FIELD_ATTR):
             a = self._host_np(f)
             if a.size:
                 _lib.check(self.lib.sg_rollout_download(self.h, f, _lib.fptr(a), a.size))
+            self._synced[f] = self._stamp(f)   # (written through the numpy view: the version counter did not move)
 
     def _push(self, fields):
-        if not self.device_resident:
-            self.sync_to_device(fields)
+        if self.device_resident:
+            return
+        if os.environ.get("SG_ROLLOUT_ALWAYS_UPLOAD") == "1":
+            return self.sync_to_device(fields)
+        stale = [f for f in fields if not self._matches(f)]
+        if stale:
+            self.sync_to_device(stale)
 
     def _pull(self, fields):
         if not self.device_resident:
@@ -125,6 +170,15 @@ class RolloutStorage(object):
         put(self.bad_masks[s + 1], bad_masks)
         self.step = (self.step + 1) % self.num_steps
         self._host_written = True
+
+    def mod_reward(self, offset, reverse_l):
+        """a2c/storage.py:86-94 (called by no shipped script): add the per-environment `offset` [N] to the rewards of the
+        `reverse_l` most recently inserted steps, walking back from the insert cursor with wrap-around.  Host tensors; the
+        write is seen by the next device call like any other in-place edit."""
+        off = offset.reshape(-1, 1) if hasattr(offset, "reshape") else np.asarray(offset, np.float32).reshape(-1, 1)
+        assert off.shape[0] == self.rewards.shape[1], (off.shape, self.rewards.shape)
+        for back in range(1, int(reverse_l) + 1):
+            self.rewards[(self.step - back) % self.num_steps] += off
 
     def after_update(self):
         """a2c/storage.py:96-101"""

@@ -1,0 +1,115 @@
+"""Drop-in mode (host tensors are the rollout, simgan_amd/storage.py): a field crosses PCIe when its host tensor changed
+since the device copy last matched it -- once per change, not once per call -- and an edit made by slicing between two
+calls, as the reference main makes them (a2c/main_gail_dyn_ppo.py:276-292), is picked up by the next device call."""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+class Box:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import simgan_amd
+    return simgan_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _filled(sg, T=16, N=8, O=5, A=3, F=7, seed=3):
+    rng = np.random.default_rng(seed)
+    ro = sg.RolloutStorage(T, N, (O,), Box((A,)), 1, F)
+    ro.rewards.copy_(ro.rewards.new_tensor(rng.standard_normal((T, N, 1)).astype(np.float32)))
+    ro.value_preds.copy_(ro.value_preds.new_tensor(rng.standard_normal((T + 1, N, 1)).astype(np.float32)))
+    ro.masks.copy_(ro.masks.new_tensor((rng.random((T + 1, N, 1)) > 0.1).astype(np.float32)))
+    ro.bad_masks.copy_(ro.bad_masks.new_tensor((rng.random((T + 1, N, 1)) > 0.05).astype(np.float32)))
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(rng.standard_normal((T + 1, N, F)).astype(np.float32)))
+    return ro, rng
+
+
+def _oracle_returns(orc, ro, nv):
+    vp = ro.value_preds.numpy()[..., 0].copy()
+    ret, _ = orc.compute_returns(ro.rewards.numpy()[..., 0], vp, ro.masks.numpy()[..., 0], ro.bad_masks.numpy()[..., 0], nv, 1, 0.99, 0.95, 1)
+    return ret
+
+
+def test_slice_edit_between_two_calls_reaches_the_device(sg, orc):
+    ro, rng = _filled(sg)
+    T, N = ro.num_steps, ro.num_processes
+    nv = rng.standard_normal(N).astype(np.float32)
+    want = _oracle_returns(orc, ro, nv)
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert_close(ro.returns.numpy()[:T, :, 0], want[:T], rtol=1e-5, what="returns, first call")
+    first = ro.bytes_uploaded
+    assert first == 4 * (T * N + 4 * (T + 1) * N), "the first call uploads the five fields it reads, once"
+    # nothing changed: nothing crosses PCIe, same result
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert ro.bytes_uploaded == first, "an unchanged rollout must not be uploaded again"
+    assert_close(ro.returns.numpy()[:T, :, 0], want[:T], rtol=1e-5, what="returns, unchanged rollout")
+    # the main's own kind of edit: assignment to a slice (a2c/main_gail_dyn_ppo.py:291)
+    ro.rewards[3] = ro.rewards[3] + 1.5
+    want2 = _oracle_returns(orc, ro, nv)
+    assert np.abs(want2[:4] - want[:4]).max() > 0.5
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert ro.bytes_uploaded == first + 4 * T * N, "exactly the edited field is uploaded"
+    assert_close(ro.returns.numpy()[:T, :, 0], want2[:T], rtol=1e-5, what="returns after rollouts.rewards[3] was edited by slicing")
+    # .copy_ into a slice, and a re-bound attribute
+    ro.masks[5].copy_(ro.masks[5] * 0.0)
+    ro.value_preds = ro.value_preds.clone() * 0.5
+    want3 = _oracle_returns(orc, ro, nv)
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert_close(ro.returns.numpy()[:T, :, 0], want3[:T], rtol=1e-5, what="returns after masks[5].copy_ and a re-bound value_preds")
+
+
+def test_write_through_a_numpy_view_needs_mark_host_written(sg, orc):
+    ro, rng = _filled(sg, seed=4)
+    T, N = ro.num_steps, ro.num_processes
+    nv = rng.standard_normal(N).astype(np.float32)
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    ro.rewards.numpy()[2] += 2.0            # torch's version counter does not see this
+    want = _oracle_returns(orc, ro, nv)
+    ro.mark_host_written()
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert_close(ro.returns.numpy()[:T, :, 0], want[:T], rtol=1e-5, what="returns after mark_host_written()")
+
+
+def test_discriminator_epochs_upload_obs_feat_once(sg):
+    """gail_epoch x update_gail_dyn + the relabel on one rollout (a2c/main_gail_dyn_ppo.py:255-292): obs_feat crosses once."""
+    T, N, F, Hd, B = 16, 8, 7, 16, 8
+    ro, rng = _filled(sg, T=T, N=N, F=F, seed=5)
+    expert = rng.standard_normal((64, F)).astype(np.float32)
+
+    class Loader:
+        def __init__(self, e, b):
+            self.expert, self.batch_size = e, b
+
+    def run(always):
+        import os
+        os.environ["SG_ROLLOUT_ALWAYS_UPLOAD"] = "1" if always else "0"
+        try:
+            D = sg.algo.gail.Discriminator(F, Hd, None, seed=2)
+            ro.mark_host_written()
+            b0 = ro.bytes_uploaded
+            losses = [D.update_gail_dyn(Loader(expert, B), ro) for _ in range(3)]
+            rms = sg.RunningMeanStd(shape=())
+            D.relabel_rewards(ro, 0.99, 0.25, rms)
+            return losses, ro.rewards.numpy().copy(), D.get_flat_params(), ro.bytes_uploaded - b0
+        finally:
+            os.environ.pop("SG_ROLLOUT_ALWAYS_UPLOAD", None)
+
+    l1, r1, p1, up1 = run(False)
+    l2, r2, p2, up2 = run(True)
+    feat_bytes, mask_bytes = 4 * (T + 1) * N * F, 4 * (T + 1) * N
+    assert up1 == feat_bytes + mask_bytes, (up1, feat_bytes, mask_bytes)
+    assert up2 == 4 * feat_bytes + mask_bytes
+    assert l1 == l2 and np.array_equal(r1, r2) and np.array_equal(p1, p2), "tracking what changed must not change any result"

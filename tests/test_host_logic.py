@@ -314,3 +314,24 @@ def test_legacy_container_fixture_is_still_legacy():
     import zipfile
     assert not zipfile.is_zipfile(os.path.join(GOLDEN, "ckpt_policy_mlp.pt"))
     assert zipfile.is_zipfile(os.path.join(GOLDEN, "ckpt_policy_split.pt"))
+
+
+def test_mod_reward_walks_back_from_the_cursor_with_wrap_around():
+    """a2c/storage.py:86-94: rewards[(step - k) % T] += offset for k = 1..reverse_l (applied twice where the walk laps)."""
+    import types
+
+    from simgan_amd.storage import RolloutStorage
+    from simgan_amd.utils import to_host_tensor
+    T, N = 5, 3
+    base = np.arange(T * N, dtype=np.float32).reshape(T, N, 1)
+    off = np.array([0.5, -1.0, 2.0], np.float32)
+    for step, back in ((2, 1), (2, 4), (0, 2), (3, 7)):
+        ro = types.SimpleNamespace(rewards=to_host_tensor(base.copy()), step=step, num_steps=T)
+        RolloutStorage.mod_reward(ro, to_host_tensor(off.copy()), back)
+        want = base.copy()
+        t = step
+        for _ in range(back):
+            t = (t - 1) % T
+            want[t, :, 0] += off
+        got = ro.rewards.numpy() if hasattr(ro.rewards, "numpy") else ro.rewards
+        assert np.array_equal(got, want), (step, back)
