@@ -128,6 +128,7 @@ TEST_PROTOTYPES = {
     "sg_test_ppo_phase_times": (C.c_int, [H, C.c_int, c_ll_p, C.c_int]),
     "sg_test_rng": (C.c_int, [H, C.c_int, C.c_int64, C.c_uint64, C.c_void_p]),
     "sg_test_tear_probe": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_ll_p]),
+    "sg_test_raise_handoff_error": (C.c_int, [H, H]),
 }
 _TEST_LIB = None
 

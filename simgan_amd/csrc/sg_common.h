@@ -126,6 +126,10 @@ struct sg_ctx {
     // event; the host reads the slot when it wants the numbers (sg_results_publish / sg_results_fetch).
     double* results = nullptr;
     hipEvent_t res_ev[8] = {nullptr};
+    // the objects whose scalars a slot holds (cleared by their destroy calls): sg_results_fetch reports a hand-off time-out of
+    // their self-waiting launches (slot words [13], [14]) against them
+    struct sg_disc* res_d[8] = {nullptr};
+    struct sg_ppo* res_a[8] = {nullptr};
 };
 #define SG_RESULT_SLOTS 8
 
@@ -174,6 +178,18 @@ struct sg_policy {
     size_t io_bytes = 0;
 };
 
+// Layout of sg_disc::d_state behind the SgOptState at its head, in unsigned words: k_disc_step4's hand-off flags (one
+// 128-byte line per chain workgroup) and its sticky time-out word; sg_ppo::d_pair: k_ppo_pair's time-out word.
+#define SG_STEP4_FLAG_WORD0 64
+#define SG_STEP4_MAX_FLAGS 1024
+#ifndef SG_STEP4_FLAG_STRIDE
+#define SG_STEP4_FLAG_STRIDE 32           // words between two workgroups' flags: one 128-byte line each
+#endif
+#define SG_STEP4_ERR_WORD (SG_STEP4_FLAG_WORD0 + SG_STEP4_MAX_FLAGS * SG_STEP4_FLAG_STRIDE)
+#define SG_STEP4_STATE_BYTES (4 * (SG_STEP4_ERR_WORD + 16))
+#define SG_PAIR_ERR_WORD 0
+unsigned* sg_disc_err_word(struct sg_disc* d);   // sg_disc.hip: k_disc_step4's sticky time-out word (device address)
+uint64_t sg_next_feat_version();   // sg_ctx.cpp: process-wide, monotonic, never 0
 struct sg_rollout {
     sg_ctx* ctx;
     int T, N, O, A, F;
@@ -184,7 +200,10 @@ struct sg_rollout {
     int64_t* d_perm = nullptr;           // [T*N] scratch permutation
     // bumped by every entry point that writes obs_feat on the device (upload, upload_step, after_update, fill_synthetic): lets
     // the discriminator's replicated data-parallel mode see that the rows it all-gathered for the previous epoch are still current
-    uint64_t feat_version = 1;
+    // content stamp of obs_feat: drawn from ONE process-wide counter (sg_next_feat_version) at creation and at every change, so a
+    // stamp is never shared by two rollouts -- a destroyed rollout's successor at the same address with the same upload history
+    // cannot be mistaken for it by a cache keyed on (pointer, rows, stamp) (sg_disc.hip: the replicated-mode all-gather cache)
+    uint64_t feat_version = sg_next_feat_version();
 };
 
 struct sg_ppo {
@@ -209,12 +228,14 @@ struct sg_ppo {
     float* d_part = nullptr;       // per-block partial sums (sumsq, losses)
     long long* d_dbg = nullptr;    // phase-timestamp buffer (test hook)
     unsigned* d_pair = nullptr;    // k_ppo_pair: error word
+    bool self_wait_failed = false; // a k_ppo_pair hand-off timed out on this object: its later updates run the two-launch step
     bool pair_primed = false;      // the row stacks were cleared for k_ppo_pair's tagged words and no other mode has run since
 };
 
 struct sg_disc {
     sg_ctx* ctx;
     SgDiscDesc desc;
+    bool self_wait_failed = false; // a k_disc_step4 hand-off timed out on this object: its later steps run as two launches
     float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr;
     float* d_slabs = nullptr;
     int n_slabs = 0;

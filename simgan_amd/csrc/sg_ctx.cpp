@@ -33,6 +33,11 @@ bool sg_ctx_exclusive(const sg_ctx* ctx) {
     return g_learner_ctx[ctx->device & 63].load(std::memory_order_relaxed) <= 1 && (ctx->world <= 1 || sg_comm_graph_ok(ctx));
 }
 
+uint64_t sg_next_feat_version() {
+    static std::atomic<uint64_t> g_next{1};
+    return g_next.fetch_add(1, std::memory_order_relaxed);
+}
+
 extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     SG_REQUIRE(out != nullptr, "sg_ctx_create: out is NULL");
     // Kernel arguments in device memory instead of host-coherent memory: every kernel of the

@@ -103,6 +103,7 @@ static void sg_step4_poll_times(const SgDiscDesc& dd, int* ta, int* tb) {
     if (const char* e = getenv("SG_STEP4_TA")) *ta = atoi(e);
     if (const char* e = getenv("SG_STEP4_TB")) *tb = atoi(e);
 }
+unsigned* sg_disc_err_word(sg_disc* d) { return reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD; }
 static void disc_refresh_images(sg_disc* d) {
     hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
 }
@@ -349,6 +350,7 @@ extern "C" int sg_disc_destroy(sg_disc* d) {
     }
 #endif
     sg_ctx_learner_gone(d->ctx);
+    for (auto& q : d->ctx->res_d) if (q == d) q = nullptr;
     float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT, d->d_erows, d->d_prows};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (d->d_eperm) (void)hipFree(d->d_eperm);
@@ -635,7 +637,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const char* fenv = getenv("SG_DISC_FUSED");
     // ... and the device is this context's alone (sg_ctx_exclusive: a launch that waits inside itself needs all its workgroups
     // resident); SG_DISC_FUSED=1 forces it (tests), =0 forbids it
-    const bool fused = thin && !sharded && !owned && !d->d_dbg && wa.xcd_map && 12 * G <= SG_STEP4_MAX_FLAGS &&
+    const bool fused = thin && !sharded && !owned && !d->d_dbg && wa.xcd_map && 12 * G <= SG_STEP4_MAX_FLAGS && !d->self_wait_failed &&
                        (fenv ? strcmp(fenv, "0") != 0 : sg_ctx_exclusive(ctx));
     const bool dbg_timing = getenv("SG_DEBUG_TIMING") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
@@ -760,6 +762,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         SG_COPY_SYNC(ctx, &err, reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD, sizeof err, hipMemcpyDeviceToHost);
         if (err) {
             SG_CHECK(hipMemsetAsync(reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD, 0, sizeof err, ctx->stream));
+            d->self_wait_failed = true;
             SG_REQUIRE(false, "sg_disc_update_gail_dyn: the weight-gradient workgroups of k_disc_step4 waited %d s for the chain "
                        "workgroups of their own launch and gave up (the discriminator's state is undefined; SG_DISC_FUSED=0 runs "
                        "the step as two launches)", (int)(SG_STEP4_TIMEOUT_TICKS / 100000000ll));

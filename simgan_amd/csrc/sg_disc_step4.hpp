@@ -75,13 +75,7 @@ struct Step4Args {          // not preloaded: read by the workgroups that copy t
 #define SG_STAMP(var) const long long var = 0
 #endif
 
-#define SG_STEP4_FLAG_WORD0 64        // unsigned words behind the SgOptState at the head of sg_disc::d_state
-#define SG_STEP4_MAX_FLAGS 1024
-#ifndef SG_STEP4_FLAG_STRIDE
-#define SG_STEP4_FLAG_STRIDE 32           // words between two workgroups' flags: one 128-byte line each
-#endif
-#define SG_STEP4_ERR_WORD (SG_STEP4_FLAG_WORD0 + SG_STEP4_MAX_FLAGS * SG_STEP4_FLAG_STRIDE)
-#define SG_STEP4_STATE_BYTES (4 * (SG_STEP4_ERR_WORD + 16))
+// (SG_STEP4_FLAG_WORD0 / _MAX_FLAGS / _FLAG_STRIDE / _ERR_WORD / _STATE_BYTES: sg_common.h, next to sg_disc::d_state)
 #define SG_STEP4_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
 
 __device__ __forceinline__ float sg_ld_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {

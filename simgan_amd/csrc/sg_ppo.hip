@@ -177,6 +177,7 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     if (!a) return 0;
     (void)hipStreamSynchronize(a->ctx->stream);
     sg_ctx_learner_gone(a->ctx);
+    for (auto& q : a->ctx->res_a) if (q == a) q = nullptr;
     float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks};
     for (float* q : ptrs) if (q) (void)hipFree(q);
     if (a->d_perms) (void)hipFree(a->d_perms);
@@ -436,7 +437,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const char* penv = getenv("SG_PPO_PAIR");
     const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
                       lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP + 2 <= d.ldH && !a->d_dbg &&
-                      (penv ? strcmp(penv, "0") != 0 : sg_ctx_exclusive(ctx));   // (=1 forces it on a shared device: tests)
+                      !a->self_wait_failed && (penv ? strcmp(penv, "0") != 0 : sg_ctx_exclusive(ctx));   // (=1 forces it on a shared device: tests)
     // the words the actor pairs swap live in the H1 row stacks: an update that ran the two-launch step left activations there,
     // and a bit pattern must never be mistaken for a tagged word -- clear them whenever the mode is (re-)entered
     if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
@@ -530,6 +531,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
         SG_COPY_SYNC(ctx, &err, a->d_pair + SG_PAIR_ERR_WORD, sizeof err, hipMemcpyDeviceToHost);
         if (err) {
             SG_CHECK(hipMemsetAsync(a->d_pair + SG_PAIR_ERR_WORD, 0, sizeof err, ctx->stream));
+            a->self_wait_failed = true;
             SG_REQUIRE(false, "sg_ppo_update: an actor workgroup of k_ppo_pair waited %d s for its partner's head outputs and gave "
                        "up (the policy's state is undefined; SG_PPO_PAIR=0 runs the step as two launches)",
                        (int)(SG_PAIR_TIMEOUT_TICKS / 100000000ll));
@@ -544,13 +546,18 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
 // One update's scalars, published without a host synchronisation: slot layout (doubles)
 //   [0..2] discriminator loss sums of the last epoch (divide by [11])   [3..5] ret_rms mean / var / count   [6] sum(1 - masks)
 //   [7] r_sa   [8..10] PPO loss sums (divide by [12])   [11] n_d   [12] ppo_epoch * num_mini_batch
-__global__ void k_publish(double* dst, const double* d_acc, const double* d_scal, const double* p_acc, double n_d, double n_p) {
+__global__ void k_publish(double* dst, const double* d_acc, const double* d_scal, const double* p_acc, double n_d, double n_p,
+                          const unsigned* d_err, const unsigned* a_err) {
     const int t = threadIdx.x;
     if (t < 3) dst[t] = d_acc ? d_acc[t] : 0.0;
     else if (t < 8) dst[t] = d_scal ? d_scal[t - 3] : 0.0;
     else if (t < 11) dst[t] = p_acc ? p_acc[t - 8] : 0.0;
     else if (t == 11) dst[t] = n_d;
     else if (t == 12) dst[t] = n_p;
+    // the sticky error words of the launches that wait inside themselves (k_disc_step4, k_ppo_pair): an update queued without
+    // a host wait has nobody else to read them
+    else if (t == 13) dst[t] = d_err ? (double)*d_err : 0.0;
+    else if (t == 14) dst[t] = a_err ? (double)*a_err : 0.0;
 }
 
 extern "C" int sg_results_publish(sg_ctx* ctx, sg_disc* d, sg_ppo* a, int slot) {
@@ -559,15 +566,40 @@ extern "C" int sg_results_publish(sg_ctx* ctx, sg_disc* d, sg_ppo* a, int slot) 
     SG_CHECK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->results + 16 * slot, d ? d->d_loss_acc : nullptr,
                        d ? d->d_scal : nullptr, a ? a->d_loss_acc : nullptr, d ? (double)d->last_n_d : 1.0,
-                       a ? (double)a->cfg.ppo_epoch * a->cfg.num_mini_batch : 1.0);
+                       a ? (double)a->cfg.ppo_epoch * a->cfg.num_mini_batch : 1.0,
+                       d ? sg_disc_err_word(d) : nullptr,
+                       (a && a->d_pair) ? a->d_pair + SG_PAIR_ERR_WORD : nullptr);
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
+    ctx->res_d[slot] = d;
+    ctx->res_a[slot] = a;
     return 0;
 }
 
+// A hand-off time-out inside a queued update surfaces HERE (the synchronous calls report it themselves): the error is
+// returned, the sticky device word is cleared and the object runs its multi-launch form from now on.
 extern "C" int sg_results_fetch(sg_ctx* ctx, int slot, double out13[13]) {
     SG_REQUIRE(ctx && out13 && slot >= 0 && slot < SG_RESULT_SLOTS, "sg_results_fetch: bad argument");
     SG_CHECK(hipEventSynchronize(ctx->res_ev[slot]));
-    memcpy(out13, ctx->results + 16 * slot, sizeof(double) * 13);
+    const double* src = ctx->results + 16 * slot;
+    memcpy(out13, src, sizeof(double) * 13);
+    const bool d_err = src[13] != 0.0, a_err = src[14] != 0.0;
+    if (d_err || a_err) {
+        SG_CHECK(hipSetDevice(ctx->device));
+        sg_disc* d = ctx->res_d[slot];
+        sg_ppo* a = ctx->res_a[slot];
+        if (d_err && d) {
+            d->self_wait_failed = true;
+            SG_CHECK(hipMemsetAsync(sg_disc_err_word(d), 0, sizeof(unsigned), ctx->stream));
+        }
+        if (a_err && a && a->d_pair) {
+            a->self_wait_failed = true;
+            SG_CHECK(hipMemsetAsync(a->d_pair + SG_PAIR_ERR_WORD, 0, sizeof(unsigned), ctx->stream));
+        }
+        SG_REQUIRE(false, "sg_results_fetch: %s%s%s waited for workgroups of its own launch and gave up during the update this slot reports "
+                   "(another process on this GPU?): the %s undefined and the slot's losses are NaN; later updates of the object run the "
+                   "multi-launch form", d_err ? "k_disc_step4" : "", d_err && a_err ? " and " : "", a_err ? "k_ppo_pair" : "",
+                   d_err && a_err ? "discriminator's and the policy's state are" : d_err ? "discriminator's state is" : "policy's state is");
+    }
     return 0;
 }

@@ -49,7 +49,6 @@ struct PpoArgs {
 };
 
 // k_ppo_pair (SplitPolicy, one launch per step): the two actor workgroups of a row group exchange their head outputs
-#define SG_PAIR_ERR_WORD 0
 #define SG_PAIR_BYTES 64
 #define SG_PAIR_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
 

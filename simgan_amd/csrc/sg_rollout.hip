@@ -65,7 +65,7 @@ extern "C" int sg_rollout_upload(sg_rollout* r, int field, const float* host, in
     if (count == 0) return 0;
     SG_CHECK(hipMemcpyAsync(r->d_field[field], host, sizeof(float) * count, hipMemcpyHostToDevice, r->ctx->stream));
     SG_CHECK(hipStreamSynchronize(r->ctx->stream));
-    if (field == SG_F_OBS_FEAT) ++r->feat_version;
+    if (field == SG_F_OBS_FEAT) r->feat_version = sg_next_feat_version();
     return 0;
 }
 
@@ -89,7 +89,7 @@ extern "C" int sg_rollout_upload_step(sg_rollout* r, int field, int t, const flo
     if (count == 0) return 0;
     SG_CHECK(hipMemcpyAsync(r->d_field[field] + (size_t)t * per, host, sizeof(float) * per, hipMemcpyHostToDevice, r->ctx->stream));
     SG_CHECK(hipStreamSynchronize(r->ctx->stream));
-    if (field == SG_F_OBS_FEAT) ++r->feat_version;
+    if (field == SG_F_OBS_FEAT) r->feat_version = sg_next_feat_version();
     return 0;
 }
 
@@ -130,7 +130,7 @@ extern "C" int sg_rollout_after_update(sg_rollout* r) {
         a.per[i] = (int64_t)r->N * r->field_width[fields[i]];
     }
     hipLaunchKernelGGL(k_after_update, dim3(32, 4), dim3(256), 0, r->ctx->stream, a);
-    ++r->feat_version;
+    r->feat_version = sg_next_feat_version();
     SG_CHECK(hipGetLastError());
     return 0;
 }
@@ -263,7 +263,7 @@ extern "C" int sg_rollout_fill_synthetic(sg_rollout* r, sg_policy* p, uint64_t s
     sg_ctx* ctx = r->ctx;
     auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     const uint64_t s = seed * 1000003ull + (uint64_t)ctx->rank;
-    ++r->feat_version;
+    r->feat_version = sg_next_feat_version();
     hipLaunchKernelGGL(k_fill_normal, blocks(r->field_count[SG_F_OBS]), dim3(256), 0, ctx->stream, r->d_field[SG_F_OBS], r->field_count[SG_F_OBS], s, 1ull);
     if (r->field_count[SG_F_OBS_FEAT])
         hipLaunchKernelGGL(k_fill_normal, blocks(r->field_count[SG_F_OBS_FEAT]), dim3(256), 0, ctx->stream, r->d_field[SG_F_OBS_FEAT], r->field_count[SG_F_OBS_FEAT], s, 2ull);

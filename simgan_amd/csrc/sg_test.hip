@@ -388,6 +388,22 @@ extern "C" int sg_test_flag_probe(sg_ctx* ctx, int mode, int np, int nc, int wor
 
 #include "sg_test_pstep.hpp"
 
+extern "C" int sg_test_raise_handoff_error(sg_disc* d, sg_ppo* a) {
+    const unsigned one = 1u;
+    if (d) {
+        SG_CHECK(hipSetDevice(d->ctx->device));
+        SG_CHECK(hipMemcpyAsync(reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD, &one, sizeof one, hipMemcpyHostToDevice, d->ctx->stream));
+        SG_CHECK(hipStreamSynchronize(d->ctx->stream));
+    }
+    if (a) {
+        SG_REQUIRE(a->d_pair, "sg_test_raise_handoff_error: this PPO object has no pair-mode state");
+        SG_CHECK(hipSetDevice(a->ctx->device));
+        SG_CHECK(hipMemcpyAsync(a->d_pair + SG_PAIR_ERR_WORD, &one, sizeof one, hipMemcpyHostToDevice, a->ctx->stream));
+        SG_CHECK(hipStreamSynchronize(a->ctx->stream));
+    }
+    return 0;
+}
+
 // Test hook: how the last update of each object was issued -- 0 direct launches, 1 replayed graph, 2 a capture was
 // refused once and the object fell back to direct launches (tests/test_gpu_comm.py).
 // ---------------------------------------------------------------------------------------------------------------

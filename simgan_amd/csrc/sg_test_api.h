@@ -29,6 +29,9 @@ SG_API int sg_test_disc_gathers(sg_disc *d, long long *out);
  * words read, largest value seen, reader lanes that saw the value change} (tools/tear_probe.py) */
 SG_API int sg_test_tear_probe(sg_ctx *ctx, int mode, int pairs4, int iters, long long *out4);
 SG_API int sg_test_rng(sg_ctx *ctx, int kind, int64_t n, uint64_t seed, void *out);
+/* raises the sticky time-out word of k_disc_step4 (d) and / or k_ppo_pair (a) on the device, as a workgroup that gave up
+ * waiting would: the next one-launch steps end at once with NaN losses (tests: how a queued update reports it) */
+SG_API int sg_test_raise_handoff_error(sg_disc *d, sg_ppo *a);
 #ifdef __cplusplus
 }
 #endif

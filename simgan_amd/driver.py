@@ -32,12 +32,20 @@ class PendingLosses(collections.abc.Mapping):
     `log_interval` updates only pays for the ones it reads.  `resolve()` returns a plain dict."""
 
     def __init__(self, ctx, slot, keys):
-        self._ctx, self._slot, self._keys, self._vals = ctx, slot, keys, None
+        self._ctx, self._slot, self._keys, self._vals, self._error = ctx, slot, keys, None, None
 
     def resolve(self):
+        """Raises SimganHipError when a launch of this update gave up waiting inside itself (sg_results_fetch); the slot is
+        read once, a later access raises the same error again."""
+        if self._error is not None:
+            raise self._error
         if self._vals is None:
             out = (C.c_double * 13)()
-            _lib.check(self._ctx.lib.sg_results_fetch(self._ctx.h, self._slot, out))
+            try:
+                _lib.check(self._ctx.lib.sg_results_fetch(self._ctx.h, self._slot, out))
+            except _lib.SimganHipError as exc:
+                self._error = exc
+                raise
             f32 = lambda x: float(np.float32(x))  # noqa: E731  (loss.item() values are float32 in the reference)
             vals = {"gail_loss": f32(out[0] / out[11]), "gail_loss_e": f32(out[1] / out[11]), "gail_loss_p": f32(out[2] / out[11]),
                     "value_loss": f32(out[8] / out[12]), "action_loss": f32(out[9] / out[12]), "dist_entropy": f32(out[10] / out[12]),
@@ -68,8 +76,8 @@ class _ResultRing(object):
     def publish(self, disc, agent, keys):
         slot = self.n % _RESULT_SLOTS
         self.n += 1
-        if self.live[slot] is not None:
-            self.live[slot].resolve()
+        if self.live[slot] is not None and self.live[slot]._error is None:
+            self.live[slot].resolve()       # (an update nobody read: its error, if any, surfaces here, eight updates later at most)
         _lib.check(self.ctx.lib.sg_results_publish(self.ctx.h, disc.h if disc is not None else None, agent.h, slot))
         self.live[slot] = PendingLosses(self.ctx, slot, keys)
         if os.environ.get("SG_UPDATE_SYNC") == "1":   # read the slot now: one host wait per update (profilers that serialise
