@@ -75,6 +75,8 @@ class PPO():
         h = _lib.H()
         _lib.check(self.lib.sg_ppo_create(self.ctx.h, actor_critic.h, C.byref(cfg), C.byref(h)))
         self.h = h
+        if hasattr(actor_critic, "_register_handle_user"):
+            actor_critic._register_handle_user(self)
         self.optimizer = _Optimizer(self, lr, eps)
         self._calls = 0
         self.seed = derive_seed(seed, 0xBADC0FFEE)   # minibatch-permutation stream (a2c/storage.py:159-162)

@@ -216,9 +216,9 @@ static int lb_open(SgLoopback* lb, const uint8_t id[128], int rank, int world) {
 
 static int lb_tmp(SgLoopback* lb, size_t bytes) {
     if (bytes <= lb->tmp_bytes) return 0;
-    if (lb->h_tmp) SG_CHECK(hipHostFree(lb->h_tmp));
+    if (lb->h_tmp) SG_CHECK(sg_host_release(lb->h_tmp));
     lb->tmp_bytes = bytes + bytes / 2 + 4096;
-    SG_CHECK(hipHostMalloc(&lb->h_tmp, lb->tmp_bytes, hipHostMallocDefault));
+    SG_CHECK(sg_host_malloc(&lb->h_tmp, lb->tmp_bytes));
     return 0;
 }
 
@@ -419,7 +419,7 @@ static_assert(sizeof(SgPeerRecord) == 96, "SgPeerRecord travels as 24 floats");
 static void peer_release(sg_ctx* ctx, SgPeer* p) {
     (void)hipSetDevice(ctx->device);
     for (int r = 0; r < SG_PEER_MAX_WORLD; ++r) if (p->mapped[r]) (void)hipIpcCloseMemHandle(p->mapped[r]);
-    if (p->own) (void)hipFree(p->own);
+    if (p->own) (void)sg_dev_free(p->own);
     delete p;
 }
 
@@ -431,7 +431,7 @@ static int peer_setup(sg_ctx* ctx) {
     const size_t flag_b = sizeof(unsigned) * 2 * (size_t)W * SG_PEER_MAX_BLOCKS * SG_PEER_FLAG_STRIDE;
     const size_t total = slot_b + flag_b + 256;
     SgPeer* p = new SgPeer();
-    if (hipMalloc(&p->own, total) != hipSuccess) { delete p; SG_REQUIRE(false, "SG_COMM_PEER: hipMalloc of %zu bytes failed", total); }
+    if (sg_dev_malloc(&p->own, total) != hipSuccess) { delete p; SG_REQUIRE(false, "SG_COMM_PEER: hipMalloc of %zu bytes failed", total); }
     int rc = 0;
     float *d_rec = nullptr, *d_all = nullptr;
     std::vector<SgPeerRecord> all((size_t)W);
@@ -442,7 +442,7 @@ static int peer_setup(sg_ctx* ctx) {
         rec.pid = (uint64_t)getpid(); rec.ptr = (uint64_t)(uintptr_t)p->own; rec.device = ctx->device;
         // (a handle is only needed by ranks in OTHER processes; a failure here surfaces there, when they try to open it)
         if (hipIpcGetMemHandle(&rec.handle, p->own) != hipSuccess) { (void)hipGetLastError(); memset(&rec.handle, 0, sizeof rec.handle); }
-        if (hipMalloc((void**)&d_rec, sizeof rec) != hipSuccess || hipMalloc((void**)&d_all, sizeof rec * (size_t)W) != hipSuccess) { sg_set_error("SG_COMM_PEER: hipMalloc failed"); rc = -1; break; }
+        if (sg_dev_malloc((void**)&d_rec, sizeof rec) != hipSuccess || sg_dev_malloc((void**)&d_all, sizeof rec * (size_t)W) != hipSuccess) { sg_set_error("SG_COMM_PEER: hipMalloc failed"); rc = -1; break; }
         if (hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: upload failed"); rc = -1; break; }
         rc = sg_comm_allgather_f32(ctx, d_rec, d_all, (int64_t)(sizeof rec / 4));
         if (rc != 0) break;
@@ -478,8 +478,8 @@ static int peer_setup(sg_ctx* ctx) {
             p->dev.flags[r] = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(base) + slot_b);
         }
     } while (0);
-    if (d_rec) (void)hipFree(d_rec);
-    if (d_all) (void)hipFree(d_all);
+    if (d_rec) (void)sg_dev_free(d_rec);
+    if (d_all) (void)sg_dev_free(d_all);
     if (rc != 0) { peer_release(ctx, p); return rc; }
     p->dev.ctrl = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(p->own) + slot_b + flag_b);
     p->dev.rank = me; p->dev.world = W;
@@ -589,7 +589,7 @@ void sg_comm_destroy(sg_ctx* ctx) {
     if (ctx->comm->peer) { peer_release(ctx, ctx->comm->peer); ctx->comm->peer = nullptr; }
     if (ctx->comm->lb) {
         SgLoopback* lb = ctx->comm->lb;
-        if (lb->h_tmp) (void)hipHostFree(lb->h_tmp);
+        if (lb->h_tmp) (void)sg_host_release(lb->h_tmp);
         if (lb->hdr) munmap(lb->hdr, lb->map_bytes);
         delete lb;
     }

@@ -6,6 +6,25 @@
 #include <string>
 #include <atomic>
 #include <vector>
+#include <mutex>
+// hipMalloc / hipFree (and the pinned-host pair) are device-wide operations: issued by one host thread while ANOTHER thread's
+// stream capture is in flight they invalidate that capture on this runtime, even in the relaxed capture mode ("operation failed
+// due to a previous error during capture"; round 4's tools/pair_stress.py: 2 of 160 rounds).  Every allocation and release
+// of the library therefore goes through these wrappers, which take the mutex the captures are serialised on (recursive: a
+// capture's own thread may grow a scratch arena before it begins to record).
+inline std::recursive_mutex& sg_capture_mutex() { static std::recursive_mutex m; return m; }
+// Object creation and destruction as a whole (allocations, the stream synchronisation and graph-exec release of a destroy
+// call, whose errors are deliberately ignored): never beside a capture in flight.  The guard also drops whatever error a
+// best-effort call of the scope left in the thread's HIP error slot, so that it cannot surface in a later, unrelated call.
+struct SgDeviceWideGuard {
+    std::lock_guard<std::recursive_mutex> l{sg_capture_mutex()};
+    ~SgDeviceWideGuard() { (void)hipGetLastError(); }
+};
+#define SG_DEVICE_WIDE() SgDeviceWideGuard _sg_device_wide_guard
+static inline hipError_t sg_dev_malloc(void** p, size_t n) { std::lock_guard<std::recursive_mutex> l(sg_capture_mutex()); return hipMalloc(p, n); }
+static inline hipError_t sg_dev_free(void* p) { std::lock_guard<std::recursive_mutex> l(sg_capture_mutex()); return hipFree(p); }
+static inline hipError_t sg_host_malloc(void** p, size_t n) { std::lock_guard<std::recursive_mutex> l(sg_capture_mutex()); return hipHostMalloc(p, n, hipHostMallocDefault); }
+static inline hipError_t sg_host_release(void* p) { std::lock_guard<std::recursive_mutex> l(sg_capture_mutex()); return hipHostFree(p); }
 
 #include "../../include/simgan_hip.h"
 #include "sg_gemm.hpp"
@@ -140,7 +159,8 @@ struct sg_ctx {
 // GPU, the deployment this library is built for -- every workgroup of those grids is resident at once and the hazard does not
 // exist.  false: more than one context of this process owns learner objects (sg_ppo / sg_disc) on the device, or the
 // context's communicator is the loopback transport (ranks of one host, typically sharing a device): the callers then use the
-// multi-launch forms.  (Other processes on the device cannot be seen from here: SG_DISC_FUSED=0 / SG_PPO_PAIR=0.)
+// multi-launch forms; so do they while ANOTHER process of this host holds learner objects on the device (a per-device advisory
+// lock under /dev/shm, sg_ctx.cpp; processes in other containers cannot be seen: SG_DISC_FUSED=0 / SG_PPO_PAIR=0).
 bool sg_ctx_exclusive(const sg_ctx* ctx);
 void sg_ctx_learner_born(sg_ctx* ctx);   // sg_ppo_create / sg_disc_create
 void sg_ctx_learner_gone(sg_ctx* ctx);   // ... and their destroy calls
@@ -310,11 +330,9 @@ __device__ __forceinline__ void sg_opt_prepare(SgOptState* st, int t) {
 // allocations and copies.
 #include <stdio.h>
 
-#include <mutex>
-inline std::mutex& sg_capture_mutex() { static std::mutex m; return m; }
 template <typename F>
 static inline int sg_try_capture(sg_ctx* ctx, hipGraphExec_t* exec, F&& enqueue) {
-    std::lock_guard<std::mutex> lock(sg_capture_mutex());
+    std::lock_guard<std::recursive_mutex> lock(sg_capture_mutex());
     hipGraph_t graph = nullptr;
     auto refuse = [&](const char* what, hipError_t e, int rc) {
         static bool told = false;

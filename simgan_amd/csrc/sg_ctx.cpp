@@ -4,6 +4,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "sg_common.h"
 
@@ -23,14 +26,65 @@ extern "C" const char* sg_version(void) { return "simgan_hip 0.1 (gfx950)"; }
 // pick a launch that waits inside itself
 static std::atomic<int> g_learner_ctx[64];
 
+// ... and OTHER processes: while a process owns learner objects on a device it holds a shared (read) record lock on
+// /dev/shm/sg_gpu_<pci bus id>.lock (SG_LOCK_DIR overrides the directory); sg_ctx_exclusive asks the kernel whether anybody else
+// holds one (F_GETLK for a write lock: a process's own locks never conflict with it, the query changes nothing, and a process
+// that dies releases its lock with its descriptors).  POSIX record locks rather than flock(): converting a flock from shared
+// to exclusive and back drops it for a moment, and two processes probing at once can each find the other gone.  What it cannot
+// see: processes in another container (their own /dev/shm) -- SG_DISC_FUSED=0 SG_PPO_PAIR=0 remain for that.
+static std::mutex g_lock_m;
+static int g_lock_fd[64];
+static bool g_lock_init = false;
+
+static void device_lock_take(int device) {
+    std::lock_guard<std::mutex> l(g_lock_m);
+    if (!g_lock_init) { for (int& f : g_lock_fd) f = -1; g_lock_init = true; }
+    if (g_lock_fd[device & 63] >= 0) return;
+    char bus[64] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", device); }
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+    const char* dir = getenv("SG_LOCK_DIR");
+    char path[256];
+    snprintf(path, sizeof path, "%s/sg_gpu_%s.lock", dir && *dir ? dir : "/dev/shm", bus);
+    const mode_t old = umask(0);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    umask(old);
+    if (fd < 0) return;      // no lock file (read-only /dev/shm?): other processes stay invisible, as before round 5
+    struct flock fl;
+    memset(&fl, 0, sizeof fl);
+    fl.l_type = F_RDLCK; fl.l_whence = SEEK_SET;
+    if (fcntl(fd, F_SETLK, &fl) != 0) { close(fd); return; }
+    g_lock_fd[device & 63] = fd;
+}
+
+static void device_lock_drop(int device) {
+    std::lock_guard<std::mutex> l(g_lock_m);
+    if (!g_lock_init || g_lock_fd[device & 63] < 0) return;
+    close(g_lock_fd[device & 63]);     // releases the record lock
+    g_lock_fd[device & 63] = -1;
+}
+
+static bool device_other_process(int device) {
+    std::lock_guard<std::mutex> l(g_lock_m);
+    if (!g_lock_init || g_lock_fd[device & 63] < 0) return false;
+    struct flock fl;
+    memset(&fl, 0, sizeof fl);
+    fl.l_type = F_WRLCK; fl.l_whence = SEEK_SET;
+    if (fcntl(g_lock_fd[device & 63], F_GETLK, &fl) != 0) return false;
+    return fl.l_type != F_UNLCK;
+}
+
 void sg_ctx_learner_born(sg_ctx* ctx) {
-    if (ctx->n_learners.fetch_add(1, std::memory_order_relaxed) == 0) g_learner_ctx[ctx->device & 63].fetch_add(1, std::memory_order_relaxed);
+    if (ctx->n_learners.fetch_add(1, std::memory_order_relaxed) == 0 && g_learner_ctx[ctx->device & 63].fetch_add(1, std::memory_order_relaxed) == 0)
+        device_lock_take(ctx->device);
 }
 void sg_ctx_learner_gone(sg_ctx* ctx) {
-    if (ctx->n_learners.fetch_sub(1, std::memory_order_relaxed) == 1) g_learner_ctx[ctx->device & 63].fetch_sub(1, std::memory_order_relaxed);
+    if (ctx->n_learners.fetch_sub(1, std::memory_order_relaxed) == 1 && g_learner_ctx[ctx->device & 63].fetch_sub(1, std::memory_order_relaxed) == 1)
+        device_lock_drop(ctx->device);
 }
 bool sg_ctx_exclusive(const sg_ctx* ctx) {
-    return g_learner_ctx[ctx->device & 63].load(std::memory_order_relaxed) <= 1 && (ctx->world <= 1 || sg_comm_graph_ok(ctx));
+    return g_learner_ctx[ctx->device & 63].load(std::memory_order_relaxed) <= 1 && (ctx->world <= 1 || sg_comm_graph_ok(ctx)) &&
+           !device_other_process(ctx->device);
 }
 
 uint64_t sg_next_feat_version() {
@@ -39,6 +93,7 @@ uint64_t sg_next_feat_version() {
 }
 
 extern "C" int sg_ctx_create(int device, sg_ctx** out) {
+    SG_DEVICE_WIDE();
     SG_REQUIRE(out != nullptr, "sg_ctx_create: out is NULL");
     // Kernel arguments in device memory instead of host-coherent memory: every kernel of the
     // 5,000-launch update chain starts by reading its kernarg segment, and that first scalar load
@@ -61,14 +116,15 @@ extern "C" int sg_ctx_create(int device, sg_ctx** out) {
     SG_REQUIRE(strstr(prop.gcnArchName, "gfx950") != nullptr,
                "sg_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     SG_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    SG_CHECK(hipHostMalloc((void**)&ctx->mailbox, sizeof(double) * 128, hipHostMallocDefault));
-    SG_CHECK(hipHostMalloc((void**)&ctx->results, sizeof(double) * 16 * SG_RESULT_SLOTS, hipHostMallocDefault));
+    SG_CHECK(sg_host_malloc((void**)&ctx->mailbox, sizeof(double) * 128));
+    SG_CHECK(sg_host_malloc((void**)&ctx->results, sizeof(double) * 16 * SG_RESULT_SLOTS));
     for (int i = 0; i < SG_RESULT_SLOTS; ++i) SG_CHECK(hipEventCreateWithFlags(&ctx->res_ev[i], hipEventDisableTiming));
     *out = ctx;
     return 0;
 }
 
 extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
+    SG_DEVICE_WIDE();
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -77,10 +133,10 @@ extern "C" int sg_ctx_destroy(sg_ctx* ctx) {
         for (auto& p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->marks) (void)hipEventDestroy(e);
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
-    if (ctx->results) (void)hipHostFree(ctx->results);
+    if (ctx->d_scratch) (void)sg_dev_free(ctx->d_scratch);
+    if (ctx->h_pinned) (void)sg_host_release(ctx->h_pinned);
+    if (ctx->mailbox) (void)sg_host_release(ctx->mailbox);
+    if (ctx->results) (void)sg_host_release(ctx->results);
     for (auto e : ctx->res_ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -128,9 +184,9 @@ extern "C" int sg_ctx_device_info(sg_ctx* ctx, char* name, int name_len, int* nu
 int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out) {
     if (bytes > ctx->scratch_bytes) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->d_scratch) SG_CHECK(hipFree(ctx->d_scratch));
+        if (ctx->d_scratch) SG_CHECK(sg_dev_free(ctx->d_scratch));
         size_t cap = bytes + bytes / 2 + 4096;
-        SG_CHECK(hipMalloc((void**)&ctx->d_scratch, cap));
+        SG_CHECK(sg_dev_malloc((void**)&ctx->d_scratch, cap));
         ctx->scratch_bytes = cap;
     }
     *out = ctx->d_scratch;
@@ -140,9 +196,9 @@ int sg_ctx_scratch(sg_ctx* ctx, size_t bytes, float** out) {
 int sg_ctx_pinned(sg_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->pinned_bytes) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->h_pinned) SG_CHECK(hipHostFree(ctx->h_pinned));
+        if (ctx->h_pinned) SG_CHECK(sg_host_release(ctx->h_pinned));
         size_t cap = bytes + bytes / 2 + 4096;
-        SG_CHECK(hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault));
+        SG_CHECK(sg_host_malloc(&ctx->h_pinned, cap));
         ctx->pinned_bytes = cap;
     }
     *out = ctx->h_pinned;
@@ -245,11 +301,11 @@ extern "C" int sg_ctx_mark_elapsed(sg_ctx* ctx, int from, int to, double* ms) {
 // north-star rollout's 40 MB).  Plain hipHostMalloc / hipHostFree; needs no context.
 extern "C" int sg_host_alloc(int64_t bytes, void** out) {
     SG_REQUIRE(out && bytes > 0, "sg_host_alloc: bad argument");
-    SG_CHECK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    SG_CHECK(sg_host_malloc(out, (size_t)bytes));
     return 0;
 }
 
 extern "C" int sg_host_free(void* p) {
-    if (p) SG_CHECK(hipHostFree(p));
+    if (p) SG_CHECK(sg_host_release(p));
     return 0;
 }

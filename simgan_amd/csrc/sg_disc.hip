@@ -267,6 +267,7 @@ __global__ void k_normalize_rewards(float* rewards, const float* scale, int T, i
 // --------------------------------------------------------------------------------------- API
 
 extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_disc** out) {
+    SG_DEVICE_WIDE();
     SG_REQUIRE(ctx && out, "sg_disc_create: NULL argument");
     SG_REQUIRE(input_dim > 0 && hidden_dim > 0, "sg_disc_create: bad dims");
     SG_CHECK(hipSetDevice(ctx->device));
@@ -280,21 +281,21 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
                "sg_disc_create: the activation tiles of a (%d x %d) discriminator need %zu bytes of LDS, the CU has %d", input_dim,
                hidden_dim, disc_chain_lds_bytes(d->desc, true), ctx->lds_bytes);
     const size_t tot = d->desc.total;
-    SG_CHECK(hipMalloc((void**)&d->d_params, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&d->d_m, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&d->d_v, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_params, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_m, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_v, sizeof(float) * tot));
     static_assert(sizeof(SgOptState) <= 4 * SG_STEP4_FLAG_WORD0, "the hand-off flags of k_disc_step4 sit behind the optimizer state");
-    SG_CHECK(hipMalloc((void**)&d->d_state, SG_STEP4_STATE_BYTES));   // SgOptState | hand-off flags | error word (k_disc_step4)
+    SG_CHECK(sg_dev_malloc((void**)&d->d_state, SG_STEP4_STATE_BYTES));   // SgOptState | hand-off flags | error word (k_disc_step4)
     SG_CHECK(hipMemsetAsync(d->d_state, 0, SG_STEP4_STATE_BYTES, ctx->stream));
-    SG_CHECK(hipMalloc((void**)&d->d_loss_acc, sizeof(double) * 8));
-    SG_CHECK(hipMalloc((void**)&d->d_scal, sizeof(double) * 8));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_loss_acc, sizeof(double) * 8));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_scal, sizeof(double) * 8));
     {
         const double scal0[8] = {0.0, 1.0, 1e-4, 0.0, 0.0, 0.0, 0.0, 0.0};   // RunningMeanStd(): mean 0, var 1, count 1e-4
         SG_CHECK(hipMemcpyAsync(d->d_scal, scal0, sizeof scal0, hipMemcpyHostToDevice, ctx->stream));
         SG_CHECK(hipStreamSynchronize(ctx->stream));
     }
     const size_t wT_f = (size_t)2 * d->desc.Hp * (d->desc.Fp + d->desc.Hp);   // images of W1, W2, W2^T, W1^T
-    SG_CHECK(hipMalloc((void**)&d->d_wT, sizeof(float) * 2 * wT_f));   // two sets: k_disc_step4 double-buffers them by step parity
+    SG_CHECK(sg_dev_malloc((void**)&d->d_wT, sizeof(float) * 2 * wT_f));   // two sets: k_disc_step4 double-buffers them by step parity
     SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * 2 * wT_f, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_m, 0, sizeof(float) * tot, ctx->stream));
@@ -306,7 +307,7 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     sg_ctx_learner_born(ctx);
 #if SG_STEP4_VERIFY
-    SG_CHECK(hipMalloc((void**)&d->d_dbg_step4, sizeof(long long) * 8 * 512 + sizeof(float) * 128 * 8 * 32 * 64 + 4 * 96 * 8 * 8 * 64 + 8 * 4 * 512));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_dbg_step4, sizeof(long long) * 8 * 512 + sizeof(float) * 128 * 8 * 32 * 64 + 4 * 96 * 8 * 8 * 64 + 8 * 4 * 512));
     SG_CHECK(hipMemset(d->d_dbg_step4, 0, sizeof(long long) * 8 * 512 + sizeof(float) * 128 * 8 * 32 * 64 + 4 * 96 * 8 * 8 * 64 + 8 * 4 * 512));
 #endif
     *out = d;
@@ -332,6 +333,7 @@ extern "C" SG_API int sg_debug_step4_chainlog(sg_disc* d, unsigned* out) {   // 
 }
 #endif
 extern "C" int sg_disc_destroy(sg_disc* d) {
+    SG_DEVICE_WIDE();
     if (!d) return 0;
     (void)hipStreamSynchronize(d->ctx->stream);
 #if SG_STEP4_VERIFY
@@ -345,18 +347,18 @@ extern "C" int sg_disc_destroy(sg_disc* d) {
                     o[0] >> 32, (o[0] >> 16) & 0xffff, (o[0] >> 8) & 0xff, (o[0] >> 4) & 1, (o[0] >> 3) & 1, (o[0] >> 1) & 3, o[0] & 1,
                     (unsigned long long)o[1] >> 32, (unsigned long long)o[1] & 0xffffffffull, o[2], o[3]);
         }
-        (void)hipFree(d->d_dbg_step4);
+        (void)sg_dev_free(d->d_dbg_step4);
         d->d_dbg_step4 = nullptr;
     }
 #endif
     sg_ctx_learner_gone(d->ctx);
     for (auto& q : d->ctx->res_d) if (q == d) q = nullptr;
     float* ptrs[] = {d->d_params, d->d_m, d->d_v, d->d_slabs, d->d_state, d->d_expert, d->d_alpha, d->d_returns, d->d_feat_all, d->d_rows, d->d_wT, d->d_erows, d->d_prows};
-    for (float* q : ptrs) if (q) (void)hipFree(q);
-    if (d->d_eperm) (void)hipFree(d->d_eperm);
-    if (d->d_pperm) (void)hipFree(d->d_pperm);
-    if (d->d_loss_acc) (void)hipFree(d->d_loss_acc);
-    if (d->d_scal) (void)hipFree(d->d_scal);
+    for (float* q : ptrs) if (q) (void)sg_dev_free(q);
+    if (d->d_eperm) (void)sg_dev_free(d->d_eperm);
+    if (d->d_pperm) (void)sg_dev_free(d->d_pperm);
+    if (d->d_loss_acc) (void)sg_dev_free(d->d_loss_acc);
+    if (d->d_scal) (void)sg_dev_free(d->d_scal);
     if (d->epoch_graph) (void)hipGraphExecDestroy(d->epoch_graph);
     delete d;
     return 0;
@@ -422,9 +424,9 @@ extern "C" int sg_disc_set_adam(sg_disc* d, const float* m, const float* v, int6
 extern "C" int sg_disc_set_expert(sg_disc* d, const float* expert, int64_t n_rows) {
     SG_REQUIRE(d && expert && n_rows > 0, "sg_disc_set_expert: bad argument");
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    if (d->d_expert) SG_CHECK(hipFree(d->d_expert));
+    if (d->d_expert) SG_CHECK(sg_dev_free(d->d_expert));
     const size_t bytes = sizeof(float) * (size_t)n_rows * d->desc.F;
-    SG_CHECK(hipMalloc((void**)&d->d_expert, bytes));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_expert, bytes));
     SG_COPY_SYNC(d->ctx, d->d_expert, expert, bytes, hipMemcpyHostToDevice);
     d->n_expert = n_rows;
     return 0;
@@ -434,8 +436,8 @@ template <typename T>
 static int ensure_cap(T** ptr, int64_t* cap, int64_t need, hipStream_t stream) {
     if (*cap >= need) return 0;
     SG_CHECK(hipStreamSynchronize(stream));
-    if (*ptr) SG_CHECK(hipFree(*ptr));
-    SG_CHECK(hipMalloc((void**)ptr, sizeof(T) * (size_t)need));
+    if (*ptr) SG_CHECK(sg_dev_free(*ptr));
+    SG_CHECK(sg_dev_malloc((void**)ptr, sizeof(T) * (size_t)need));
     *cap = need;
     return 0;
 }
@@ -599,8 +601,8 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)2 * 12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (d->d_slabs) SG_CHECK(hipFree(d->d_slabs));
-        SG_CHECK(hipMalloc((void**)&d->d_slabs, sizeof(float) * (2 * ops_f + part_f + grad_f)));
+        if (d->d_slabs) SG_CHECK(sg_dev_free(d->d_slabs));
+        SG_CHECK(sg_dev_malloc((void**)&d->d_slabs, sizeof(float) * (2 * ops_f + part_f + grad_f)));
         d->n_slabs = G;
         // ld-padding entries of the flat gradient are never written by k_disc_wgrad: they must read as zero
         SG_CHECK(hipMemsetAsync(d->d_slabs, 0, sizeof(float) * (2 * ops_f + part_f + grad_f), ctx->stream));
@@ -815,8 +817,8 @@ static int ensure_returns(sg_disc* d, int n) {
     SG_REQUIRE(d->returns_none || d->returns_n == n,
                "Discriminator.returns holds %d rows but %d were passed (the reference would broadcast-fail)", d->returns_n, n);
     SG_CHECK(hipStreamSynchronize(d->ctx->stream));
-    if (d->d_returns) SG_CHECK(hipFree(d->d_returns));
-    SG_CHECK(hipMalloc((void**)&d->d_returns, sizeof(float) * n));
+    if (d->d_returns) SG_CHECK(sg_dev_free(d->d_returns));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_returns, sizeof(float) * n));
     SG_CHECK(hipMemsetAsync(d->d_returns, 0, sizeof(float) * n, d->ctx->stream));
     d->returns_n = n;
     return 0;

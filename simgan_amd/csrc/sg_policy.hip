@@ -226,6 +226,7 @@ extern "C" int sg_policy_create(sg_ctx* ctx, int kind, int obs_dim, int act_dim,
 
 extern "C" int sg_policy_create2(sg_ctx* ctx, int kind, int obs_dim, int act_dim, int hidden, int num_feet, int critic_hidden,
                                  sg_policy** out) {
+    SG_DEVICE_WIDE();
     SG_REQUIRE(ctx && out, "sg_policy_create: NULL argument");
     SG_REQUIRE(critic_hidden >= 0, "sg_policy_create2: bad critic_hidden");
     SG_REQUIRE(kind == SG_POLICY_MLP || kind == SG_POLICY_SPLIT, "sg_policy_create: unknown kind %d", kind);
@@ -243,17 +244,18 @@ extern "C" int sg_policy_create2(sg_ctx* ctx, int kind, int obs_dim, int act_dim
     SG_REQUIRE(fwd_lds_bytes(p->desc, 1, true) <= (size_t)ctx->lds_bytes - 1024,
                "sg_policy_create: one 16-row activation tile of this policy (obs %d, hidden %d: %zu bytes) does not fit the %d-byte LDS",
                obs_dim, hidden, fwd_lds_bytes(p->desc, 1, true), ctx->lds_bytes);
-    SG_CHECK(hipMalloc((void**)&p->d_params, sizeof(float) * p->desc.total));
+    SG_CHECK(sg_dev_malloc((void**)&p->d_params, sizeof(float) * p->desc.total));
     SG_CHECK(hipMemsetAsync(p->d_params, 0, sizeof(float) * p->desc.total, ctx->stream));
     *out = p;
     return 0;
 }
 
 extern "C" int sg_policy_destroy(sg_policy* p) {
+    SG_DEVICE_WIDE();
     if (!p) return 0;
     (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->d_params) (void)hipFree(p->d_params);
-    if (p->d_io) (void)hipFree(p->d_io);
+    if (p->d_params) (void)sg_dev_free(p->d_params);
+    if (p->d_io) (void)sg_dev_free(p->d_io);
     delete p;
     return 0;
 }
@@ -298,8 +300,8 @@ static int policy_host_call(sg_policy* p, const float* obs, int n, int mode, con
     const size_t need = sizeof(float) * (f_obs + 2 * f_na + 3 * (size_t)n);
     if (need > p->io_bytes) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (p->d_io) SG_CHECK(hipFree(p->d_io));
-        SG_CHECK(hipMalloc((void**)&p->d_io, need + need / 2));
+        if (p->d_io) SG_CHECK(sg_dev_free(p->d_io));
+        SG_CHECK(sg_dev_malloc((void**)&p->d_io, need + need / 2));
         p->io_bytes = need + need / 2;
     }
     float* d_io = p->d_io;
@@ -475,8 +477,8 @@ extern "C" int sg_policy_act_ensemble(sg_policy* const* policies, int n_policies
     const size_t need = sizeof(float) * (f_obs + 2 * f_na + 3 * (size_t)n);
     if (need > p0->io_bytes) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (p0->d_io) SG_CHECK(hipFree(p0->d_io));
-        SG_CHECK(hipMalloc((void**)&p0->d_io, need + need / 2));
+        if (p0->d_io) SG_CHECK(sg_dev_free(p0->d_io));
+        SG_CHECK(sg_dev_malloc((void**)&p0->d_io, need + need / 2));
         p0->io_bytes = need + need / 2;
     }
     float* d_obs = p0->d_io;

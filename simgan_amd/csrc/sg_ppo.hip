@@ -142,6 +142,7 @@ static void launch_ppo_bwd(sg_ctx* ctx, int MT, const SgPolicyDesc& d, dim3 grid
 
 // ---------------------------------------------------------------------------------- PPO API
 extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg, sg_ppo** out) {
+    SG_DEVICE_WIDE();
     SG_REQUIRE(ctx && p && cfg && out, "sg_ppo_create: NULL argument");
     SG_REQUIRE(cfg->ppo_epoch > 0 && cfg->num_mini_batch > 0, "sg_ppo_create: ppo_epoch and num_mini_batch must be positive");
     // a policy whose trunk does not fit a CU's LDS runs on the global-weight instances; only the 16-row tiles must fit
@@ -152,16 +153,16 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
     sg_ppo* a = new sg_ppo();
     a->ctx = ctx; a->policy = p; a->cfg = *cfg;
     const size_t tot = (size_t)p->desc.total + 8;
-    SG_CHECK(hipMalloc((void**)&a->d_m, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&a->d_v, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&a->d_grad, sizeof(float) * tot));
-    SG_CHECK(hipMalloc((void**)&a->d_state, sizeof(SgOptState)));
-    SG_CHECK(hipMalloc((void**)&a->d_loss_acc, sizeof(double) * 8));
-    SG_CHECK(hipMalloc((void**)&a->d_part, sizeof(float) * ((tot + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS + 8)));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_m, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_v, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_grad, sizeof(float) * tot));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_state, sizeof(SgOptState)));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_loss_acc, sizeof(double) * 8));
+    SG_CHECK(sg_dev_malloc((void**)&a->d_part, sizeof(float) * ((tot + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS + 8)));
     SG_CHECK(hipMemsetAsync(a->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_v, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(a->d_loss_acc, 0, sizeof(double) * 8, ctx->stream));
-    SG_CHECK(hipMalloc((void**)&a->d_pair, SG_PAIR_BYTES));            // k_ppo_pair: error word
+    SG_CHECK(sg_dev_malloc((void**)&a->d_pair, SG_PAIR_BYTES));            // k_ppo_pair: error word
     SG_CHECK(hipMemsetAsync(a->d_pair, 0, SG_PAIR_BYTES, ctx->stream));
     SgOptState st;
     memset(&st, 0, sizeof st);
@@ -174,16 +175,17 @@ extern "C" int sg_ppo_create(sg_ctx* ctx, sg_policy* p, const sg_ppo_config* cfg
 }
 
 extern "C" int sg_ppo_destroy(sg_ppo* a) {
+    SG_DEVICE_WIDE();
     if (!a) return 0;
     (void)hipStreamSynchronize(a->ctx->stream);
     sg_ctx_learner_gone(a->ctx);
     for (auto& q : a->ctx->res_a) if (q == a) q = nullptr;
     float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks};
-    for (float* q : ptrs) if (q) (void)hipFree(q);
-    if (a->d_perms) (void)hipFree(a->d_perms);
-    if (a->d_loss_acc) (void)hipFree(a->d_loss_acc);
-    if (a->d_dbg) (void)hipFree(a->d_dbg);
-    if (a->d_pair) (void)hipFree(a->d_pair);
+    for (float* q : ptrs) if (q) (void)sg_dev_free(q);
+    if (a->d_perms) (void)sg_dev_free(a->d_perms);
+    if (a->d_loss_acc) (void)sg_dev_free(a->d_loss_acc);
+    if (a->d_dbg) (void)sg_dev_free(a->d_dbg);
+    if (a->d_pair) (void)sg_dev_free(a->d_pair);
     if (a->steps_graph) (void)hipGraphExecDestroy(a->steps_graph);
     delete a;
     return 0;
@@ -332,8 +334,8 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // permutations
     if (a->perms_cap < (int64_t)E * TN) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (a->d_perms) SG_CHECK(hipFree(a->d_perms));
-        SG_CHECK(hipMalloc((void**)&a->d_perms, sizeof(int64_t) * (size_t)E * TN));
+        if (a->d_perms) SG_CHECK(sg_dev_free(a->d_perms));
+        SG_CHECK(sg_dev_malloc((void**)&a->d_perms, sizeof(int64_t) * (size_t)E * TN));
         a->perms_cap = (int64_t)E * TN;
     }
     a->last_perm_count = owned ? 0 : (int64_t)E * TN;   // owned mode: the device holds this rank's share only
@@ -380,10 +382,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     const size_t stack_f = (size_t)d.n_trunks * mbp * (2 * (size_t)d.ldH + ldP);
     if (a->slabs_cap < slab_f || a->stacks_cap < epoch_f + stack_f) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
-        if (a->d_slabs) SG_CHECK(hipFree(a->d_slabs));
-        if (a->d_stacks) SG_CHECK(hipFree(a->d_stacks));
-        SG_CHECK(hipMalloc((void**)&a->d_slabs, sizeof(float) * slab_f));
-        SG_CHECK(hipMalloc((void**)&a->d_stacks, sizeof(float) * (epoch_f + stack_f)));
+        if (a->d_slabs) SG_CHECK(sg_dev_free(a->d_slabs));
+        if (a->d_stacks) SG_CHECK(sg_dev_free(a->d_stacks));
+        SG_CHECK(sg_dev_malloc((void**)&a->d_slabs, sizeof(float) * slab_f));
+        SG_CHECK(sg_dev_malloc((void**)&a->d_stacks, sizeof(float) * (epoch_f + stack_f)));
         a->slabs_cap = slab_f;
         a->stacks_cap = epoch_f + stack_f;
         a->scratch_key = 0;
@@ -436,8 +438,10 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // the two actor workgroups of a row group exchanging their head outputs inside it (k_ppo_pair).  SG_PPO_PAIR=0: two launches.
     const char* penv = getenv("SG_PPO_PAIR");
     const bool pair = !gw && !fused && !crit_first && d.kind == SG_POLICY_SPLIT && d.n_trunks == 3 && MT <= 2 &&
-                      lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP + 2 <= d.ldH && !a->d_dbg &&
+                      lds_fc <= (size_t)ctx->lds_bytes && 3 * G <= ctx->num_cu && 2 * ldP + 2 <= std::min(d.trunk[0].ldH, d.trunk[1].ldH) && !a->d_dbg &&
                       !a->self_wait_failed && (penv ? strcmp(penv, "0") != 0 : sg_ctx_exclusive(ctx));   // (=1 forces it on a shared device: tests)
+    // (the tagged words live in the ACTOR trunks' H1 rows, indexed with the trunk's own ldH: d.ldH is the widest trunk's, which a
+    // critic rebuilt wider than the actors -- sg_policy_create2 -- would make too generous a bound)
     // the words the actor pairs swap live in the H1 row stacks: an update that ran the two-launch step left activations there,
     // and a bit pattern must never be mistaken for a tagged word -- clear them whenever the mode is (re-)entered
     if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));

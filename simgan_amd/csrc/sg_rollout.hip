@@ -16,6 +16,7 @@ int sg_policy_forward_device(sg_policy* p, const float* d_obs, int n, int mode, 
 
 extern "C" int sg_rollout_create(sg_ctx* ctx, int T, int N, int obs_dim, int act_dim, int feat_dim,
                                  sg_rollout** out) {
+    SG_DEVICE_WIDE();
     SG_REQUIRE(ctx && out, "sg_rollout_create: NULL argument");
     SG_REQUIRE(T > 0 && N > 0 && obs_dim > 0 && act_dim > 0 && feat_dim >= 0, "sg_rollout_create: bad dims");
     SG_CHECK(hipSetDevice(ctx->device));
@@ -28,7 +29,7 @@ extern "C" int sg_rollout_create(sg_ctx* ctx, int T, int N, int obs_dim, int act
         r->field_width[f] = width[f];
         r->field_count[f] = (int64_t)slots[f] * N * width[f];
         const size_t bytes = sizeof(float) * (size_t)(r->field_count[f] > 0 ? r->field_count[f] : 1);
-        SG_CHECK(hipMalloc((void**)&r->d_field[f], bytes));
+        SG_CHECK(sg_dev_malloc((void**)&r->d_field[f], bytes));
         SG_CHECK(hipMemsetAsync(r->d_field[f], 0, bytes, ctx->stream));
     }
     // masks / bad_masks start at one (a2c/storage.py:50-54)
@@ -41,11 +42,12 @@ extern "C" int sg_rollout_create(sg_ctx* ctx, int T, int N, int obs_dim, int act
 }
 
 extern "C" int sg_rollout_destroy(sg_rollout* r) {
+    SG_DEVICE_WIDE();
     if (!r) return 0;
     (void)hipStreamSynchronize(r->ctx->stream);
     for (int f = 0; f < SG_F_COUNT; ++f)
-        if (r->d_field[f]) (void)hipFree(r->d_field[f]);
-    if (r->d_perm) (void)hipFree(r->d_perm);
+        if (r->d_field[f]) (void)sg_dev_free(r->d_field[f]);
+    if (r->d_perm) (void)sg_dev_free(r->d_perm);
     delete r;
     return 0;
 }

@@ -24,6 +24,8 @@ class PolicyEnsemble(object):
         self.obs_dim, self.act_dim = self.policies[0].obs_dim, self.policies[0].act_dim
         self.lib = self.policies[0].lib
         self._handles = (_lib.H * len(self.policies))(*[p.h for p in self.policies])
+        for p in self.policies:
+            p._register_handle_user(self)
         self.seed = derive_seed(seed, 0xE5E, per_instance=True)
         self._calls = 0
 

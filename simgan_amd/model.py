@@ -36,6 +36,12 @@ class _PolicyBase(object):
         self.seed = derive_seed(0, 0x5EED, per_instance=True)   # action-noise stream; re-derived from the constructor seed below
         self._act_calls = 0
 
+    def _register_handle_user(self, obj):
+        """Objects that keep this policy's device handle (PPO, PolicyEnsemble) announce themselves: reset_critic refuses to
+        replace the handle while one of them is alive."""
+        import weakref
+        self.__dict__.setdefault("_handle_users", []).append(weakref.ref(obj))
+
     def __del__(self):
         try:
             h = self.__dict__.get("h")
@@ -247,8 +253,14 @@ class Policy(_PolicyBase):
         rng = np.random.default_rng(seed)
         sd = self.state_dict()
         if self.critic_hidden != 64:
-            old = self.h
+            users = [u for u in self.__dict__.get("_handle_users", ()) if u() is not None]
+            if users:   # they hold the device handle that is about to be replaced: refuse instead of freeing it under them
+                raise RuntimeError(f"reset_critic: {len(users)} object(s) built on this policy ({', '.join(type(u()).__name__ for u in users)}) "
+                                   "hold its device handle, which a critic of another width replaces; call reset_critic first "
+                                   "(a2c/main.py:85 precedes :149) or rebuild them afterwards")
+            old, seed_, calls_ = self.h, self.seed, self._act_calls
             self._create(self.obs_dim, self.act_dim, self.hidden_size, self.num_feet, self.ctx, critic_hidden=64)
+            self.seed, self._act_calls = seed_, calls_     # the action-noise stream goes on where it was
             self.lib.sg_policy_destroy(old)
         for name, shape in self.param_shapes():
             if name.startswith("base.critic"):

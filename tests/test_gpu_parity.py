@@ -639,6 +639,18 @@ def test_refine_iteration_golden(sg, fixture):
     import pickle
     q2 = pickle.loads(pickle.dumps(q))          # survives the package's own pickle with its critic width
     assert q2.critic_hidden == 64 and np.array_equal(q2.get_flat_params(), q.get_flat_params())
+    # ... and is refused while an agent built on the policy holds the handle it would replace (the main's order is :85 then :149);
+    # the action-noise stream goes on where it was
+    q3 = sg.Policy((5,), Box((2,)), base_kwargs={"hidden_size": 32})
+    seed3 = q3.seed
+    agent3 = sg.algo.PPO(q3, 0.2, 1, 1, 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    with pytest.raises(RuntimeError, match="hold its device handle"):
+        q3.reset_critic((5,))
+    del agent3
+    import gc
+    gc.collect()
+    q3.reset_critic((5,))
+    assert q3.critic_hidden == 64 and q3.seed == seed3
 
 
 def test_collect_then_update_device_resident_equals_drop_in(sg):
