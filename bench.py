@@ -245,7 +245,7 @@ def cpu_baseline(w, expert, budget_s):
     return out
 
 
-PROF_SLOTS = ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam", "disc_step"]
+PROF_SLOTS = ["disc_chain", "disc_wgrad", "ppo_fwd", "ppo_bwd", "ppo_reduce", "relabel_fwd", "ppo_adam", "disc_step", "comm_f32"]
 
 
 def load_tdoc(workload):
@@ -579,6 +579,7 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (the unchanged main's call sequence on host tensors)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline measurement (+ cpu baseline unless --no-cpu-baseline)")
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
+    ap.add_argument("--no-other-allreduce", action="store_true", help="N > 1: skip timing the other form of the per-step all-reduce (peer mesh / base communicator)")
     ap.add_argument("--init-timeout", type=float, default=480.0, help="watchdog budget (s) for start-up: imports, context, communicator, problem build")
     ap.add_argument("--stage-timeout", type=float, default=420.0, help="watchdog budget (s) for each later stage (warm-up, timed region, profile pass, ...)")
     ap.add_argument("--no-dp-check", action="store_true", help="N > 1: skip the replica-consistency check after the warm-up")
@@ -758,7 +759,12 @@ def main():
                                        "path, NOT a scaling measurement"),
                            "kind": kind, "nranks_reported_by_rccl": ctx.comm_info()[1], "rank0_reported_by_rccl": ctx.comm_info()[0],
                            "disc_mode": "sharded" if ctx.disc_sharded else "replicated",
-                           "peer_allreduce": ctx.comm_peer()}   # SG_COMM_PEER=1: the per-step gradient all-reduce as one peer-write kernel
+                           "peer_allreduce": ctx.comm_peer(),   # SG_COMM_PEER=1: the per-step gradient all-reduce as one peer-write kernel
+                           # the per-step float32 gradient all-reduce of the headline run, bracketed by HIP events in the separate
+                           # profile pass (device time from reaching the collective to leaving it: the wait for the slowest rank included)
+                           "allreduce_us": round(1e3 * prof["comm_f32"][0] / max(prof["comm_f32"][1], 1), 2),
+                           "allreduce_count_per_update": prof["comm_f32"][1],
+                           "allreduce_form": "peer mesh" if ctx.comm_peer() else kind}
     else:
         out = None
     # N > 1: the discriminator has two data-parallel modes.  `value` is the default (replicated:
@@ -796,6 +802,46 @@ def main():
         ctx.set_disc_dp(not ctx.disc_sharded)
         if rank == 0:
             out["comm"]["disc_other_mode"] = alt
+    # N > 1: the OTHER form of the per-step all-reduce -- the peer mesh when the headline ran on the base communicator (RCCL),
+    # the base communicator when SG_COMM_PEER=1 -- on the same communicator, toggled collectively (sg_ctx_comm_set_peer), so
+    # that the first multi-GPU run comes back with both timed.  Own watchdog; a failure leaves an `error` entry.
+    if (world > 1 or force_alt) and not args.no_other_allreduce:
+        import threading
+        k2 = max(2, args.steps // 2)
+        was_peer = ctx.comm_peer()
+        form = "base communicator" if was_peer else "peer mesh"
+        field = "base" if was_peer else "peer"
+        budget = max(120.0, 10.0 * elapsed * (k2 + 3) / args.steps)
+
+        def give_up2():
+            if rank == 0:
+                out["comm"][field] = dict(form=form, error=f"no result within {budget:.0f} s; measurement abandoned")
+                emit(out)
+            os._exit(0)
+
+        dog3 = threading.Timer(budget, give_up2)
+        dog3.daemon = True
+        dog3.start()
+        try:
+            dog.stage(f"[{form}] switching the all-reduce form (collective set-up)", 1e9)
+            ctx.comm_set_peer(not was_peer)
+            e3, pr3, _ = timed(k2, 2, label=f"[{form}] ")
+            dog.stage(f"[{form}] per-kernel HIP-event pass", 1e9)
+            prof3 = profile_pass(ctx, learner)
+            leg = dict(form=form, steps=k2, ms_per_step=round(1e3 * e3 / k2, 3), value=round(w["T"] * w["N"] * world * k2 / e3, 1),
+                       allreduce_us=round(1e3 * prof3["comm_f32"][0] / max(prof3["comm_f32"][1], 1), 2),
+                       per_rank_ms_per_step=[round(1e3 * x / k2, 3) for x in pr3])
+        except Exception as exc:   # every rank gets the set-up's error (it is collective): the headline stands
+            leg = dict(form=form, error=str(exc)[:400])
+        dog3.cancel()
+        try:
+            if ctx.comm_peer() != was_peer:
+                ctx.comm_set_peer(was_peer)
+        except Exception as exc:
+            leg["restore_error"] = str(exc)[:200]
+        dog.stage("all-reduce forms done / cpu baseline / output", 1e9)
+        if rank == 0:
+            out["comm"][field] = leg
     if world == 1 and not force_alt and not args.headline_only:
         # Everything below is reported BESIDE `value`, never as it; the headline is complete.  A leg that fails or runs out
         # of its budget leaves an `error` entry: the line is not lost (the stage watchdog prints what it has and ends the run).

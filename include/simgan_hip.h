@@ -65,6 +65,11 @@ SG_API int sg_ctx_comm_init(sg_ctx *ctx, const uint8_t id[128], int rank, int wo
  * peer-mapped device memory instead of a library collective (SG_COMM_PEER=1 in the environment at sg_ctx_comm_init: opt-in,
  * built over either transport). */
 SG_API int sg_ctx_comm_kind(sg_ctx *ctx, int *kind);
+/* Collective over an initialised communicator (every rank, same argument): 1 builds the peer mesh for the per-step float32
+ * gradient all-reduce (what SG_COMM_PEER=1 does at sg_ctx_comm_init), 0 returns to the base communicator.  The outcome is
+ * collective: every rank leaves with the mesh or every rank gets the error.  No counterpart in the reference (single process,
+ * a2c/main_gail_dyn_ppo.py:64); bench.py times both all-reduce forms with it on the first multi-GPU run. */
+SG_API int sg_ctx_comm_set_peer(sg_ctx *ctx, int enable);
 /* rank / world as the communicator itself reports them (ncclCommUserRank / ncclCommCount) once it exists. */
 SG_API int sg_ctx_comm_info(sg_ctx *ctx, int *rank, int *world);
 /* Discriminator data-parallel mode for world > 1: 0 = replicated (default: one all-gather of
@@ -267,7 +272,8 @@ SG_API int sg_host_free(void *p);
 /* ------------------------------------------------------------- measurement */
 /* HIP-event timing of the dominant kernels on the library's stream since the last reset:
  * which = 0 k_disc_chain (discriminator step, serial part), 1 k_disc_wgrad (weight gradients + Adam),
- * 2 k_ppo_fwd, 3 k_ppo_bwd, 4 k_ppo_reduce, 5 relabel forward, 6 k_ppo_adam (clip + Adam).
+ * 2 k_ppo_fwd, 3 k_ppo_bwd, 4 k_ppo_reduce, 5 relabel forward, 6 k_ppo_adam (clip + Adam), 7 k_disc_step4 (the one-launch
+ * discriminator step), 8 the per-step float32 gradient all-reduce (N > 1: RCCL, loopback or the peer mesh, whichever runs).
  * Enabled by sg_ctx_profile(ctx, 1); adds start/stop events to every launch (do not enable inside
  * the timed bench region). */
 SG_API int sg_ctx_profile(sg_ctx *ctx, int enable);

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "sg_comm_loopback_id": (C.c_int, [c_u8_p]),
     "sg_ctx_comm_init": (C.c_int, [H, c_u8_p, C.c_int, C.c_int]),
     "sg_ctx_comm_kind": (C.c_int, [H, c_int_p]),
+    "sg_ctx_comm_set_peer": (C.c_int, [H, C.c_int]),
     "sg_ctx_comm_info": (C.c_int, [H, c_int_p, c_int_p]),
     "sg_ctx_set_disc_dp": (C.c_int, [H, C.c_int]),
     "sg_policy_create": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
@@ -302,6 +303,10 @@ class Context:
         k = C.c_int(0)
         check(self.lib.sg_ctx_comm_kind(self.h, C.byref(k)))
         return bool(k.value & 4)
+
+    def comm_set_peer(self, enable):
+        """Collective: every rank calls it with the same value (include/simgan_hip.h: sg_ctx_comm_set_peer)."""
+        check(self.lib.sg_ctx_comm_set_peer(self.h, 1 if enable else 0))
 
     def comm_info(self):
         """(rank, world) as the communicator itself reports them."""

@@ -418,72 +418,146 @@ static_assert(sizeof(SgPeerRecord) == 96, "SgPeerRecord travels as 24 floats");
 
 static void peer_release(sg_ctx* ctx, SgPeer* p) {
     (void)hipSetDevice(ctx->device);
+    if (p->own && p->launches) {     // a collective that gave up left its word up (sticky): say so once, on the way out
+        unsigned err = 0;
+        const size_t off = sizeof(float) * 2 * (size_t)ctx->world * SG_PEER_MAX_FLOATS + sizeof(unsigned) * 2 * (size_t)ctx->world * SG_PEER_MAX_BLOCKS * SG_PEER_FLAG_STRIDE;
+        if (hipMemcpy(&err, reinterpret_cast<uint8_t*>(p->own) + off + 8, sizeof err, hipMemcpyDeviceToHost) == hipSuccess && err)
+            fprintf(stderr, "[simgan_hip] rank %d: a peer-mesh all-reduce gave up waiting for a peer's flags (20 s) during this run; the vectors of that step were NaN\n", ctx->rank);
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < SG_PEER_MAX_WORLD; ++r) if (p->mapped[r]) (void)hipIpcCloseMemHandle(p->mapped[r]);
     if (p->own) (void)sg_dev_free(p->own);
     delete p;
 }
 
-// Builds the mesh over the base communicator that is already up.  Every rank must call it (it contains a collective).
+// Builds the mesh over the base communicator that is already up.  Every rank must call it: it contains two collectives -- the
+// all-gather of the buffer records and ONE status all-reduce at the end, which makes the outcome collective: either every
+// rank leaves with the mesh or none does (a rank whose hipIpcOpenMemHandle failed used to be left on the base communicator
+// while its peers ran the mesh kernel and waited 20 s for it).  A rank that fails locally still takes part in both.
+// SG_COMM_PEER_FAIL_RANK=r (test hook): rank r behaves as if opening a peer's handle had failed.
 static int peer_setup(sg_ctx* ctx) {
     const int W = ctx->world, me = ctx->rank;
     SG_REQUIRE(W <= SG_PEER_MAX_WORLD, "SG_COMM_PEER: at most %d ranks (world is %d)", SG_PEER_MAX_WORLD, W);
+    SG_REQUIRE(!ctx->comm->peer, "SG_COMM_PEER: the mesh is already up");
     const size_t slot_b = sizeof(float) * 2 * (size_t)W * SG_PEER_MAX_FLOATS;
     const size_t flag_b = sizeof(unsigned) * 2 * (size_t)W * SG_PEER_MAX_BLOCKS * SG_PEER_FLAG_STRIDE;
     const size_t total = slot_b + flag_b + 256;
     SgPeer* p = new SgPeer();
-    if (sg_dev_malloc(&p->own, total) != hipSuccess) { delete p; SG_REQUIRE(false, "SG_COMM_PEER: hipMalloc of %zu bytes failed", total); }
-    int rc = 0;
+    int rc = 0;            // this rank's own outcome; the error text of the first local failure is kept
+    char why[512] = "";
+    auto fail = [&](int code, const char* fmt, auto... args) {
+        if (rc != 0) return;
+        rc = code;
+        if constexpr (sizeof...(args) == 0) snprintf(why, sizeof why, "%s", fmt);
+        else snprintf(why, sizeof why, fmt, args...);
+    };
     float *d_rec = nullptr, *d_all = nullptr;
     std::vector<SgPeerRecord> all((size_t)W);
-    do {
-        if (hipMemsetAsync(p->own, 0, total, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: clearing the slot buffer failed"); rc = -1; break; }
-        SgPeerRecord rec;
-        memset(&rec, 0, sizeof rec);
-        rec.pid = (uint64_t)getpid(); rec.ptr = (uint64_t)(uintptr_t)p->own; rec.device = ctx->device;
-        // (a handle is only needed by ranks in OTHER processes; a failure here surfaces there, when they try to open it)
-        if (hipIpcGetMemHandle(&rec.handle, p->own) != hipSuccess) { (void)hipGetLastError(); memset(&rec.handle, 0, sizeof rec.handle); }
-        if (sg_dev_malloc((void**)&d_rec, sizeof rec) != hipSuccess || sg_dev_malloc((void**)&d_all, sizeof rec * (size_t)W) != hipSuccess) { sg_set_error("SG_COMM_PEER: hipMalloc failed"); rc = -1; break; }
-        if (hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: upload failed"); rc = -1; break; }
-        rc = sg_comm_allgather_f32(ctx, d_rec, d_all, (int64_t)(sizeof rec / 4));
-        if (rc != 0) break;
-        if (hipMemcpyAsync(all.data(), d_all, sizeof rec * (size_t)W, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { sg_set_error("SG_COMM_PEER: download failed"); rc = -1; break; }
+    SgPeerRecord rec;
+    memset(&rec, 0, sizeof rec);
+    rec.pid = (uint64_t)getpid(); rec.device = ctx->device;
+    // the two staging buffers of the collectives themselves: without them this rank cannot take part at all (the others then
+    // meet the base communicator's own time-out); nothing else below returns before the status all-reduce
+    if (sg_dev_malloc((void**)&d_rec, sizeof rec) != hipSuccess || sg_dev_malloc((void**)&d_all, sizeof rec * (size_t)W) != hipSuccess) {
+        if (d_rec) (void)sg_dev_free(d_rec);
+        delete p;
+        SG_REQUIRE(false, "SG_COMM_PEER: hipMalloc of the set-up staging buffers failed");
+    }
+    if (sg_dev_malloc(&p->own, total) != hipSuccess) { p->own = nullptr; (void)hipGetLastError(); fail(-1, "SG_COMM_PEER: hipMalloc of %zu bytes failed", total); }
+    else if (hipMemsetAsync(p->own, 0, total, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) fail(-1, "SG_COMM_PEER: clearing the slot buffer failed");
+    rec.ptr = (uint64_t)(uintptr_t)p->own;
+    rec.pad[0] = rc != 0;      // "this rank has no buffer to offer"
+    // (a handle is only needed by ranks in OTHER processes; a failure here surfaces there, when they try to open it)
+    if (p->own && hipIpcGetMemHandle(&rec.handle, p->own) != hipSuccess) { (void)hipGetLastError(); memset(&rec.handle, 0, sizeof rec.handle); }
+    bool gathered = false;
+    if (hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) fail(-1, "SG_COMM_PEER: upload failed");
+    {
+        const int g = sg_comm_allgather_f32(ctx, d_rec, d_all, (int64_t)(sizeof rec / 4));
+        if (g != 0) fail(g, "SG_COMM_PEER: the all-gather of the buffer records failed: %s", sg_last_error());
+        else if (hipMemcpyAsync(all.data(), d_all, sizeof rec * (size_t)W, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) fail(-1, "SG_COMM_PEER: download failed");
+        else gathered = true;
+    }
+    if (gathered) {
+        for (int r = 0; r < W; ++r) if (all[(size_t)r].pad[0]) fail(-1, "SG_COMM_PEER: rank %d could not allocate its slot buffer", r);
         // Ranks that are contexts of ONE process share that process's hardware queues (HIP maps streams onto GPU_MAX_HW_QUEUES
         // of them, 4 by default): a collective kernel that waits for the kernel of a rank whose stream sits behind it on the
-        // same queue would wait for ever.  (One process per rank -- the deployment -- has a queue set per rank.)
+        // same queue would wait for ever.  (One process per rank -- the deployment -- has a queue set per rank.)  The count says
+        // nothing about WHICH queue a stream lands on: in-process ranks are a test arrangement, run with as many queues as ranks.
         int same_pid = 0;
         for (int r = 0; r < W; ++r) same_pid += all[(size_t)r].pid == (uint64_t)getpid();
         const char* hq = getenv("GPU_MAX_HW_QUEUES");
         const int n_hq = hq && atoi(hq) > 0 ? atoi(hq) : 4;
-        if (same_pid > n_hq) {
-            sg_set_error("SG_COMM_PEER: %d ranks are contexts of one process, which has %d hardware queues (GPU_MAX_HW_QUEUES): "
-                         "streams sharing a queue cannot wait for each other's kernels; use one process per rank", same_pid, n_hq);
-            rc = -2;
-        }
+        if (same_pid > n_hq)
+            fail(-2, "SG_COMM_PEER: %d ranks are contexts of one process, which has %d hardware queues (GPU_MAX_HW_QUEUES): "
+                     "streams sharing a queue cannot wait for each other's kernels; use one process per rank", same_pid, n_hq);
+        const char* inj = getenv("SG_COMM_PEER_FAIL_RANK");
         for (int r = 0; r < W && rc == 0; ++r) {
             void* base = nullptr;
             if (r == me) base = p->own;
+            else if (inj && atoi(inj) == me) fail(-1, "SG_COMM_PEER: hipIpcOpenMemHandle of rank %d's buffer failed: injected by SG_COMM_PEER_FAIL_RANK", r);
             else if (all[(size_t)r].pid == (uint64_t)getpid()) {      // a context of this process: its pointer is valid here
                 base = (void*)(uintptr_t)all[(size_t)r].ptr;
                 if (all[(size_t)r].device != ctx->device) {           // ... on another device: peer access (idempotent)
                     const hipError_t e = hipDeviceEnablePeerAccess(all[(size_t)r].device, 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { sg_set_error("SG_COMM_PEER: no peer access from device %d to device %d: %s", ctx->device, all[(size_t)r].device, hipGetErrorString(e)); rc = -1; }
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) fail(-1, "SG_COMM_PEER: no peer access from device %d to device %d: %s", ctx->device, all[(size_t)r].device, hipGetErrorString(e));
                     (void)hipGetLastError();
                 }
             } else {
                 const hipError_t e = hipIpcOpenMemHandle(&base, all[(size_t)r].handle, hipIpcMemLazyEnablePeerAccess);
-                if (e != hipSuccess) { sg_set_error("SG_COMM_PEER: hipIpcOpenMemHandle of rank %d's buffer failed: %s", r, hipGetErrorString(e)); rc = -1; (void)hipGetLastError(); }
+                if (e != hipSuccess) { fail(-1, "SG_COMM_PEER: hipIpcOpenMemHandle of rank %d's buffer failed: %s", r, hipGetErrorString(e)); (void)hipGetLastError(); }
                 else p->mapped[r] = base;
             }
             p->dev.slots[r] = reinterpret_cast<float*>(base);
             p->dev.flags[r] = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(base) + slot_b);
         }
-    } while (0);
-    if (d_rec) (void)sg_dev_free(d_rec);
-    if (d_all) (void)sg_dev_free(d_all);
-    if (rc != 0) { peer_release(ctx, p); return rc; }
+    }
+    // the outcome, made collective: how many ranks failed
+    float failed = rc != 0 ? 1.f : 0.f;
+    int n_failed = -1;
+    if (hipMemcpyAsync(d_rec, &failed, sizeof failed, hipMemcpyHostToDevice, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess &&
+        sg_comm_allreduce_f32(ctx, d_rec, 1) == 0 &&
+        hipMemcpyAsync(&failed, d_rec, sizeof failed, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
+        n_failed = (int)(failed + 0.5f);
+    (void)sg_dev_free(d_rec);
+    (void)sg_dev_free(d_all);
+    if (rc != 0 || n_failed != 0) {
+        peer_release(ctx, p);
+        (void)hipGetLastError();
+        if (rc != 0) { sg_set_error("%s (%d of %d ranks failed; no rank uses the mesh)", why, n_failed, W); return rc; }
+        if (n_failed < 0) { sg_set_error("SG_COMM_PEER: the status all-reduce of the set-up failed; this rank does not use the mesh"); return -1; }
+        sg_set_error("SG_COMM_PEER: %d of %d ranks could not set the mesh up (their own messages say why); no rank uses it", n_failed, W);
+        return -3;
+    }
     p->dev.ctrl = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(p->own) + slot_b + flag_b);
     p->dev.rank = me; p->dev.world = W;
     ctx->comm->peer = p;
+    return 0;
+}
+
+// The mesh's sticky time-out word (device address), or NULL without a mesh: published with an update's scalars
+// (sg_results_publish) so that a collective that gave up is reported at the next read of the losses.
+unsigned* sg_comm_peer_err_word(sg_ctx* ctx) { return (ctx->comm && ctx->comm->peer) ? ctx->comm->peer->dev.ctrl + 2 : nullptr; }
+bool sg_comm_peer_on(const sg_ctx* ctx) { return ctx->comm && ctx->comm->peer; }
+
+// Collective: every rank of the communicator calls it with the same `enable`.  1: build the mesh over the base communicator
+// (what SG_COMM_PEER=1 does at sg_ctx_comm_init); 0: drop it, the small all-reduces go back to the base communicator.
+extern "C" int sg_ctx_comm_set_peer(sg_ctx* ctx, int enable) {
+    SG_REQUIRE(ctx && ctx->comm, "sg_ctx_comm_set_peer: no communicator (sg_ctx_comm_init first)");
+    SG_CHECK(hipSetDevice(ctx->device));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    if (enable) return ctx->comm->peer ? 0 : peer_setup(ctx);
+    if (ctx->comm->peer) {
+        // every rank's last mesh collective is complete before any rank unmaps: one collective on the base communicator
+        float* w = nullptr;
+        SG_TRY(sg_ctx_scratch(ctx, 64, &w));
+        SG_CHECK(hipMemsetAsync(w, 0, 64, ctx->stream));
+        SgPeer* p = ctx->comm->peer;
+        ctx->comm->peer = nullptr;
+        const int rc = sg_comm_allreduce_f32(ctx, w, 4);
+        (void)hipStreamSynchronize(ctx->stream);
+        peer_release(ctx, p);
+        return rc;
+    }
     return 0;
 }
 
@@ -598,12 +672,24 @@ void sg_comm_destroy(sg_ctx* ctx) {
     ctx->comm = nullptr;
 }
 
-int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n) {
-    SG_REQUIRE(ctx->comm, "all-reduce requested but no communicator (call sg_ctx_comm_init)");
+static int allreduce_f32(sg_ctx* ctx, float* dev, int64_t n) {
     if (ctx->comm->peer && n > 0 && n <= SG_PEER_MAX_FLOATS) return peer_allreduce(ctx, dev, n);
     if (ctx->comm->lb) return lb_collective(ctx, 0, dev, dev, (size_t)n, 4);
     SG_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat32, ncclSum, ctx->comm->comm, ctx->stream));
     return 0;
+}
+
+// The per-step gradient all-reduce.  With profiling on (sg_ctx_profile: bench.py's separate HIP-event pass) the collective is
+// bracketed by two events on the stream -- what the device spends between reaching it and leaving it, the wait for the
+// slowest peer included -- and accumulated in slot SG_PROF_COMM_F32.
+int sg_comm_allreduce_f32(sg_ctx* ctx, float* dev, int64_t n) {
+    SG_REQUIRE(ctx->comm, "all-reduce requested but no communicator (call sg_ctx_comm_init)");
+    if (!ctx->profile) return allreduce_f32(ctx, dev, n);
+    const SgEv ev = sg_prof_events(ctx, SG_PROF_COMM_F32);
+    SG_CHECK(hipEventRecord(ev.a, ctx->stream));
+    const int rc = allreduce_f32(ctx, dev, n);
+    SG_CHECK(hipEventRecord(ev.b, ctx->stream));
+    return rc;
 }
 
 int sg_comm_allreduce_f64(sg_ctx* ctx, double* dev, int64_t n) {

@@ -110,7 +110,7 @@ void sg_disc_unpad(const SgDiscDesc& d, const float* padded, float* flat);
 
 // ------------------------------------------------------------------------------------ handles
 enum { SG_PROF_DISC_CHAIN = 0, SG_PROF_DISC_WGRAD, SG_PROF_PPO_FWD, SG_PROF_PPO_BWD,
-       SG_PROF_PPO_REDUCE, SG_PROF_RELABEL, SG_PROF_PPO_ADAM, SG_PROF_DISC_STEP, SG_PROF_COUNT };
+       SG_PROF_PPO_REDUCE, SG_PROF_RELABEL, SG_PROF_PPO_ADAM, SG_PROF_DISC_STEP, SG_PROF_COMM_F32, SG_PROF_COUNT };
 
 struct SgProfSlot {
     double total_ms = 0.0;
@@ -208,6 +208,8 @@ struct sg_policy {
 #define SG_STEP4_ERR_WORD (SG_STEP4_FLAG_WORD0 + SG_STEP4_MAX_FLAGS * SG_STEP4_FLAG_STRIDE)
 #define SG_STEP4_STATE_BYTES (4 * (SG_STEP4_ERR_WORD + 16))
 #define SG_PAIR_ERR_WORD 0
+unsigned* sg_comm_peer_err_word(struct sg_ctx* ctx);   // sg_comm.cpp: the peer mesh's sticky time-out word, or NULL
+bool sg_comm_peer_on(const struct sg_ctx* ctx);
 unsigned* sg_disc_err_word(struct sg_disc* d);   // sg_disc.hip: k_disc_step4's sticky time-out word (device address)
 uint64_t sg_next_feat_version();   // sg_ctx.cpp: process-wide, monotonic, never 0
 struct sg_rollout {

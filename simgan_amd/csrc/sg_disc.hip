@@ -729,7 +729,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
                                   (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size,
-                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | (fused ? 8u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
+                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | (fused ? 8u : 0u) | (sg_comm_peer_on(ctx) ? 16u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }

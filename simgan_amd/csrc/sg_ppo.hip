@@ -512,7 +512,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0) + (sg_comm_peer_on(ctx) ? 32 : 0)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
@@ -551,7 +551,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
 //   [0..2] discriminator loss sums of the last epoch (divide by [11])   [3..5] ret_rms mean / var / count   [6] sum(1 - masks)
 //   [7] r_sa   [8..10] PPO loss sums (divide by [12])   [11] n_d   [12] ppo_epoch * num_mini_batch
 __global__ void k_publish(double* dst, const double* d_acc, const double* d_scal, const double* p_acc, double n_d, double n_p,
-                          const unsigned* d_err, const unsigned* a_err) {
+                          const unsigned* d_err, const unsigned* a_err, const unsigned* peer_err) {
     const int t = threadIdx.x;
     if (t < 3) dst[t] = d_acc ? d_acc[t] : 0.0;
     else if (t < 8) dst[t] = d_scal ? d_scal[t - 3] : 0.0;
@@ -562,6 +562,7 @@ __global__ void k_publish(double* dst, const double* d_acc, const double* d_scal
     // a host wait has nobody else to read them
     else if (t == 13) dst[t] = d_err ? (double)*d_err : 0.0;
     else if (t == 14) dst[t] = a_err ? (double)*a_err : 0.0;
+    else if (t == 15) dst[t] = peer_err ? (double)__hip_atomic_load(peer_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // the peer mesh's (sg_comm.cpp)
 }
 
 extern "C" int sg_results_publish(sg_ctx* ctx, sg_disc* d, sg_ppo* a, int slot) {
@@ -572,7 +573,7 @@ extern "C" int sg_results_publish(sg_ctx* ctx, sg_disc* d, sg_ppo* a, int slot) 
                        d ? d->d_scal : nullptr, a ? a->d_loss_acc : nullptr, d ? (double)d->last_n_d : 1.0,
                        a ? (double)a->cfg.ppo_epoch * a->cfg.num_mini_batch : 1.0,
                        d ? sg_disc_err_word(d) : nullptr,
-                       (a && a->d_pair) ? a->d_pair + SG_PAIR_ERR_WORD : nullptr);
+                       (a && a->d_pair) ? a->d_pair + SG_PAIR_ERR_WORD : nullptr, sg_comm_peer_err_word(ctx));
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
     ctx->res_d[slot] = d;
@@ -588,6 +589,12 @@ extern "C" int sg_results_fetch(sg_ctx* ctx, int slot, double out13[13]) {
     const double* src = ctx->results + 16 * slot;
     memcpy(out13, src, sizeof(double) * 13);
     const bool d_err = src[13] != 0.0, a_err = src[14] != 0.0;
+    if (src[15] != 0.0) {
+        SG_CHECK(hipSetDevice(ctx->device));
+        if (unsigned* w = sg_comm_peer_err_word(ctx)) SG_CHECK(hipMemsetAsync(w, 0, sizeof(unsigned), ctx->stream));
+        SG_REQUIRE(false, "sg_results_fetch: rank %d: a peer-mesh all-reduce (SG_COMM_PEER) waited 20 s for a peer's flags and gave up "
+                   "during or before the update this slot reports; that step's gradient was NaN on this rank", ctx->rank);
+    }
     if (d_err || a_err) {
         SG_CHECK(hipSetDevice(ctx->device));
         sg_disc* d = ctx->res_d[slot];

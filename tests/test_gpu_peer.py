@@ -95,14 +95,73 @@ def case_refused(tw):
         os.environ["GPU_MAX_HW_QUEUES"] = os.environ.pop("GPU_MAX_HW_QUEUES_SAVED") or "8"
 
 
-THREAD_CASES = [("ppo", 2, "mlp_small"), ("ppo", 3, "mlp_small"), ("ppo", 4, "northstar"), ("ppo", 4, "split"), ("ppo", 8, "northstar"),
+def case_setup_failure_is_collective(tw):
+    """One rank cannot open a peer's buffer (injected): EVERY rank's set-up returns an error -- the failing rank its own, the
+    others "1 of 2 ranks could not ..." -- and nobody is left running the mesh kernel against a rank that is not in it.  The same
+    communicators then take the mesh through sg_ctx_comm_set_peer, run a PPO update over it, drop it again, and agree with the
+    run that never had one."""
+    from simgan_amd import _lib
+    os.environ["SG_COMM_PEER"] = "1"
+    os.environ["SG_COMM_PEER_FAIL_RANK"] = "1"
+    seen = {}
+
+    def rank_fn_init(rank, ctx):
+        return None
+
+    # (a) at sg_ctx_comm_init: run_ranks' own comm_init raises on every rank
+    import threading
+    uid = _lib.comm_loopback_id()
+    errs = [None, None]
+
+    def body(rank):
+        try:
+            _lib.Context(0).comm_init(uid, rank, 2)
+        except _lib.SimganHipError as exc:
+            errs[rank] = str(exc)
+
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hangs in the set-up of a mesh another rank failed to join"
+    assert errs[1] and "injected by SG_COMM_PEER_FAIL_RANK" in errs[1] and "no rank uses the mesh" in errs[1], errs
+    assert errs[0] and "1 of 2 ranks could not set the mesh up" in errs[0], errs
+    # (b) toggled on a live communicator
+    os.environ["SG_COMM_PEER"] = "0"
+    os.environ.pop("SG_COMM_PEER_FAIL_RANK")
+
+    def rank_fn(rank, ctx):
+        assert not ctx.comm_peer()
+        os.environ["SG_COMM_PEER_FAIL_RANK"] = "0"        # (process-wide: both ranks read it; only rank 0 matches)
+        try:
+            ctx.comm_set_peer(True)
+        except _lib.SimganHipError as exc:
+            seen[rank] = str(exc)
+        assert not ctx.comm_peer()
+        return None
+
+    tw.run_ranks(2, rank_fn, timeout_s=120)
+    assert "injected" in seen.get(0, "") and "1 of 2 ranks" in seen.get(1, ""), seen
+    os.environ.pop("SG_COMM_PEER_FAIL_RANK")
+
+    def rank_fn2(rank, ctx):
+        ctx.comm_set_peer(True)
+        assert ctx.comm_peer()
+        ctx.comm_set_peer(False)
+        assert not ctx.comm_peer()
+        ctx.comm_set_peer(True)
+        return ctx.comm_peer()
+
+    assert tw.run_ranks(2, rank_fn2, timeout_s=120) == [True, True]
+
+
+THREAD_CASES = [("setup_failure",), ("ppo", 2, "mlp_small"), ("ppo", 3, "mlp_small"), ("ppo", 4, "northstar"), ("ppo", 4, "split"), ("ppo", 8, "northstar"),
                 ("disc_sharded", 2, "northstar"), ("disc_sharded", 4, "split"), ("refused",)]
 
 
 def main():
     import test_gpu_world as tw
     for case in THREAD_CASES:
-        {"ppo": case_ppo, "disc_sharded": case_disc_sharded, "refused": case_refused}[case[0]](tw, *case[1:])
+        {"ppo": case_ppo, "disc_sharded": case_disc_sharded, "refused": case_refused, "setup_failure": case_setup_failure_is_collective}[case[0]](tw, *case[1:])
         print("OK", *case, flush=True)
 
 
