@@ -252,6 +252,8 @@ struct sg_ppo {
     unsigned* d_pair = nullptr;    // k_ppo_pair: error word
     bool self_wait_failed = false; // a k_ppo_pair hand-off timed out on this object: its later updates run the two-launch step
     bool pair_primed = false;      // the row stacks were cleared for k_ppo_pair's tagged words and no other mode has run since
+    unsigned long long* d_small = nullptr;   // k_ppo_small: the trunks' tagged words [2][2][SG_SMALL_WORDS]
+    bool small_primed = false;     // ... cleared since the step counter was last set (sg_ppo_set_adam)
 };
 
 struct sg_disc {

@@ -378,7 +378,7 @@ __device__ __forceinline__ void sg_layer_nn_u(const float* dY, int ldy, const fl
 // the first MFMA, accumulates both contributions in registers and stores the panel once.  The
 // optional second operand pair lets a gradient with two terms (e.g. dW2 = d2^T bu1 + z2b^T h1 in
 // the gradient penalty) be formed without a read-modify-write of G.   R = 16*KC rows.
-template <int KC, int NTN, bool TWO>
+template <int KC, int NTN, bool TWO, bool NT = true>
 __device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, int lda, const float* bp,
                                             const float* bp2, int ldb, float* G, int ldg, bool accumulate) {
     float a[TWO ? 2 : 1][KC][4], b[TWO ? 2 : 1][KC][4][NTN];
@@ -418,14 +418,19 @@ __device__ __forceinline__ void sg_tn_panel(const float* ap, const float* ap2, i
         sg_f4 v = sg_f4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
         // a fresh gradient panel is written once and read by a later kernel: a streaming store lets it drain
         // to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back
+        // (NT = false: G is an LDS buffer -- k_ppo_small keeps the gradient on chip -- where a streaming store does not exist)
         if (accumulate) *p = *p + v;
-        else __builtin_nontemporal_store(v, p);
+        else if (NT) __builtin_nontemporal_store(v, p);
+        else {   // (element by element: a plain 16-byte vector store of MFMA results does not get through this compiler's back end)
+            float* q = G + li * ldg + 16 * j + 4 * lq;
+            q[0] = acc[j][0]; q[1] = acc[j][1]; q[2] = acc[j][2]; q[3] = acc[j][3];
+        }
     }
 }
 
 // NW_HINT: the number of waves the caller launches with when that is more than 4 (a compile-time hint, so that with
 // compile-time Mp / Np the strip width and the panel switch below still fold to one case; 0 = 8-tile strips).
-template <int KC, int NW_HINT = 0>
+template <int KC, int NW_HINT = 0, bool NT = true>
 __device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const float* X, int ldx,
                                             const float* dY2, const float* X2, int Mp, int Np,
                                             float* G, int ldg, bool accumulate) {
@@ -446,8 +451,8 @@ __device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const floa
         float* g = G + (size_t)(tm * 16) * ldg + tb * bw * 16;
 #define SG_PANEL(N)                                                                              \
     do {                                                                                         \
-        if (dY2) sg_tn_panel<KC, N, true>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);       \
-        else sg_tn_panel<KC, N, false>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);          \
+        if (dY2) sg_tn_panel<KC, N, true, NT>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);   \
+        else sg_tn_panel<KC, N, false, NT>(ap, ap2, ldy, bp, bp2, ldx, g, ldg, accumulate);      \
     } while (0)
         switch (ntn) {
             case 8: SG_PANEL(8); break; case 7: SG_PANEL(7); break; case 6: SG_PANEL(6); break;
@@ -458,10 +463,10 @@ __device__ __forceinline__ void sg_grad_tn2(const float* dY, int ldy, const floa
     }
 }
 
-template <int KC, int NW_HINT = 0>
+template <int KC, int NW_HINT = 0, bool NT = true>
 __device__ __forceinline__ void sg_grad_tn(const float* dY, int ldy, const float* X, int ldx, int Mp,
                                            int Np, float* G, int ldg, bool accumulate) {
-    sg_grad_tn2<KC, NW_HINT>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
+    sg_grad_tn2<KC, NW_HINT, NT>(dY, ldy, X, ldx, nullptr, nullptr, Mp, Np, G, ldg, accumulate);
 }
 
 // sum over the 16 lanes of one DPP row, result in all 16 lanes: quad butterflies, then the half-row and row mirrors

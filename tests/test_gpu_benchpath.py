@@ -163,11 +163,8 @@ def test_bench_path_two_updates_vs_oracle(workload):
             rewards, d_ret, rms = orc.relabel(F, Hd, dp, obs_feat, masks, bench.GAMMA, -r_sa, d_ret, rms)
         else:
             rewards = rewards_in
-        tracks = {}
-        for name, (p_, m_, v_, t_) in (("continuous", (pi, pi_adam.m, pi_adam.v, pi_adam.t.value)), ("reseeded", (p_dev0, m0, v0, t0_))):
-            if it == 0 and name == "reseeded":
-                tracks[name] = tracks["continuous"]
-                continue
+        def run_track(start):
+            p_, m_, v_, t_ = start
             p_start = np.array(p_, np.float32, copy=True)
             ad = orc.AdamState(p_start.size)
             ad.m[:], ad.v[:] = m_, v_
@@ -176,7 +173,17 @@ def test_bench_path_two_updates_vs_oracle(workload):
             ret, vp2 = orc.compute_returns(rewards, vp, masks, bad, nv, 1, bench.GAMMA, bench.LAM, 1)
             p_end = p_start.copy()
             pl = orc.ppo_update(d, p_end, ad, cfg, obs, actions, vp2, ret, logp, perms)
-            tracks[name] = dict(start=p_start, end=p_end, adam=ad, nv=nv, ret=ret, pl=pl)
+            return dict(start=p_start, end=p_end, adam=ad, nv=nv, ret=ret, pl=pl)
+
+        starts = {"continuous": (pi, pi_adam.m.copy(), pi_adam.v.copy(), pi_adam.t.value), "reseeded": (p_dev0, m0, v0, t0_)}
+        if it == 0:     # the first update starts from the same state on both tracks
+            tracks = {"continuous": run_track(starts["continuous"])}
+            tracks["reseeded"] = tracks["continuous"]
+        else:           # the two tracks of the second update are independent: side by side (the C oracle releases the GIL)
+            import concurrent.futures
+            with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+                futs = {name: pool.submit(run_track, st) for name, st in starts.items()}
+                tracks = {name: f.result() for name, f in futs.items()}
         pi = tracks["continuous"]["end"]
         pi_adam = tracks["continuous"]["adam"]
         t_orc += time.perf_counter() - t0

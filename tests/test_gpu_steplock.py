@@ -81,6 +81,11 @@ def test_ppo_epochs_step_locked_to_the_oracle(workload):
         logp, vp, ret = _flat2(ro.action_log_probs).copy(), _flat2(ro.value_preds).copy(), _flat2(ro.returns).copy()
         epochs = []
         record["phases"][phase] = epochs
+        # The E epochs on the device first (each starts where the previous one ended), every epoch's start and end state kept;
+        # then the same E epochs through the scalar oracle, each FROM THE DEVICE'S STATE at its start -- independent of one
+        # another, so they run side by side on the host's cores (the C calls release the GIL): the same 10 epochs per phase in a
+        # tenth of the wall time.
+        dev_epochs = []
         for e in range(E):
             p0 = pol.get_flat_params()
             m0, v0, t0 = step_agent.get_adam()
@@ -88,15 +93,26 @@ def test_ppo_epochs_step_locked_to_the_oracle(workload):
             perms = step_agent.last_perms()
             assert perms.shape == (1, T * N) and np.array_equal(np.sort(perms[0]), np.arange(T * N))
             p_hip = pol.get_flat_params()
-            # ---- the same epoch through the oracle, from the device's state
-            tic = time.perf_counter()
+            m1, v1, t1 = step_agent.get_adam()
+            dev_epochs.append((p0, m0, v0, t0, losses_hip, perms, p_hip, m1, v1, t1))
+
+        def oracle_epoch(st):
+            p0, m0, v0, t0, _, perms = st[:6]
             ad = orc.AdamState(p0.size)
             ad.m[:], ad.v[:] = m0, v0
             ad.t.value = t0
             p_orc = p0.copy()
             losses_orc = orc.ppo_update(d, p_orc, ad, cfg, obs, actions, vp, ret, logp, perms)
-            t_orc += time.perf_counter() - tic
-            m1, v1, t1 = step_agent.get_adam()
+            return p_orc, losses_orc, ad
+
+        import concurrent.futures
+        tic = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(E, (os.cpu_count() or 2) - 1))) as pool:
+            orc_out = list(pool.map(oracle_epoch, dev_epochs))
+        t_orc += time.perf_counter() - tic
+        for e in range(E):
+            p0, m0, v0, t0, losses_hip, perms, p_hip, m1, v1, t1 = dev_epochs[e]
+            p_orc, losses_orc, ad = orc_out[e]
             assert t1 == t0 + M == ad.t.value
             # ---- compare
             lh, lo = np.asarray(losses_hip, np.float64), np.asarray(losses_orc, np.float64)

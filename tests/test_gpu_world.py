@@ -554,7 +554,7 @@ def test_bench_self_launch_propagates_a_failing_rank():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--loopback", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                        "--no-other-disc-mode"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--no-other-disc-mode", "--no-other-allreduce"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     # ... and the launcher's SIGTERM to the surviving rank 0 must not lose the line: it says what happened and where
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -577,7 +577,7 @@ def test_bench_watchdog_reports_a_rank_that_never_arrives():
         env.pop(k, None)
     t0 = time.time()
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--loopback", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-other-disc-mode", "--init-timeout", "60"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--no-other-disc-mode", "--no-other-allreduce", "--init-timeout", "30"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     took = time.time() - t0
     assert r.returncode != 0 and took < 240, (r.returncode, took, r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -596,7 +596,7 @@ def test_bench_replica_check_is_reported(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--loopback", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-other-disc-mode"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--no-other-disc-mode", "--no-other-allreduce"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["replica_check"]["ok"] is True and out["replica_check"]["ranks"] == 2, out["replica_check"]
