@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 run_prof() {  # name, rocprofv3 args...
     local name=$1; shift
     rm -rf /tmp/prof_${wl}_$name
-    timeout 600 rocprofv3 "$@" -d /tmp/prof_${wl}_$name -o $name --output-format rocpd -- python $root/bench.py --workload $wl --steps ${PROF_STEPS:-2} --warmup ${PROF_WARMUP:-1} --no-cpu-baseline > /tmp/prof_${wl}_$name.out 2> /tmp/prof_${wl}_$name.err
+    timeout 600 rocprofv3 "$@" -d /tmp/prof_${wl}_$name -o $name --output-format rocpd -- python $root/bench.py --workload $wl --steps ${PROF_STEPS:-2} --warmup ${PROF_WARMUP:-1} --no-cpu-baseline --headline-only > /tmp/prof_${wl}_$name.out 2> /tmp/prof_${wl}_$name.err
     find /tmp/prof_${wl}_$name -name "*.db" | head -1
 }
 if [ "${PMC_ONLY:-0}" != "1" ]; then
@@ -32,7 +32,9 @@ python $root/tools/rocpd_pmc.py $db > $out/${tag}_${wl}_pmc_write_size.txt
 unset SG_UPDATE_SYNC
 cd $root
 [ "${PMC_ONLY:-0}" = "1" ] && exit 0
-timeout 900 python bench.py --workload $wl --cpu-seconds 8 > $out/${tag}_${wl}_bench.json 2> $out/${tag}_${wl}_bench.err
+# (the north-star line is the driver's own command: it also carries the other workloads' brief runs and the drop-in legs)
+extra=$([ "$wl" = "northstar" ] && echo "" || echo "--headline-only")
+timeout 900 python bench.py --workload $wl --cpu-seconds 8 $extra > $out/${tag}_${wl}_bench.json 2> $out/${tag}_${wl}_bench.err
 head -12 $out/${tag}_${wl}_kernel_trace.txt
 head -6 $out/${tag}_${wl}_pmc_fetch_size.txt
 head -6 $out/${tag}_${wl}_pmc_write_size.txt
