@@ -45,7 +45,9 @@ print("RESULT " + json.dumps({"tag": tag, "sha": h, "before": before, "during": 
 
 
 def _run(tags, rdv, updates=40):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # a lock directory of their own: the processes of this test see EACH OTHER, not the pytest process (which may still hold
+    # learner objects of earlier tests, and with them its own lock on the device)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SG_LOCK_DIR=rdv)
     env.pop("SG_DISC_FUSED", None)
     env.pop("SG_PPO_PAIR", None)
     procs = [subprocess.Popen([sys.executable, "-c", CHILD, t, str(len(tags)), rdv, str(updates)], cwd=ROOT, env=env,
