@@ -220,14 +220,31 @@ class Discriminator(object):
         d_in = np.concatenate([_lib.as_f32(state), _lib.as_f32(action)], axis=1)
         return self.predict_reward_combined(d_in, gamma, masks, offset)
 
-    def predict_prob_single_step(self, s, a, s_n):
-        """a2c/algo/gail.py:212-217: sigmoid(D(cat(s, a, s_n))) as a Python float (one transition)."""
-        x = np.concatenate([_lib.as_f32(s).reshape(-1), _lib.as_f32(a).reshape(-1), _lib.as_f32(s_n).reshape(-1)])
+    def predict_prob_single_step(self, state, action, s_n=None):
+        """a2c/algo/gail.py:212-217: sigmoid(D(cat(state, action))).  The reference's two-argument form takes row batches
+        [n, .] and returns the probabilities as an [n, 1] tensor; with a third block `s_n` (a GAIL-dyn transition s, a, s')
+        and ONE transition it returns a Python float, as the environments' discriminator-in-the-loop code consumes it."""
+        if s_n is None:
+            st, ac = _lib.as_f32(state), _lib.as_f32(action)
+            if st.ndim == 1:
+                st, ac = st.reshape(1, -1), ac.reshape(1, -1)
+            x = np.ascontiguousarray(np.concatenate([st, ac], axis=1))
+            assert x.shape[1] == self.input_dim, (x.shape, self.input_dim)
+            return self.predict_prob(x)
+        x = np.concatenate([_lib.as_f32(state).reshape(-1), _lib.as_f32(action).reshape(-1), _lib.as_f32(s_n).reshape(-1)])
         assert x.size == self.input_dim, (x.size, self.input_dim)
         x = np.ascontiguousarray(x.reshape(1, -1))
         out = np.empty(1, np.float32)
         _lib.check(self.lib.sg_disc_predict_prob(self.h, _lib.fptr(x), 1, _lib.fptr(out)))
         return float(out[0])
+
+    def compute_grad_pen(self, *a, **k):
+        """a2c/algo/gail.py:53-89: in the reference a differentiable term that `update` / `update_gail_dyn` add to their loss
+        before `.backward()` -- nothing else calls it.  Here the penalty AND its double backward are formed inside the update
+        step's kernels (k_disc_step4 / k_disc_chain), so there is no stand-alone differentiable penalty to hand out."""
+        raise NotImplementedError("compute_grad_pen[_combined] is fused into update() / update_gail_dyn() (a2c/algo/gail.py:133,179 are its only callers)")
+
+    compute_grad_pen_combined = compute_grad_pen
 
     def predict_prob(self, d_in):
         """Batched form of predict_prob_single_step: sigmoid(D(x)) for rows x [n, F] -> [n, 1]."""

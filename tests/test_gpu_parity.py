@@ -718,6 +718,11 @@ def test_predict_prob_single_step(sg, orc):
     s_ref = 1.0 / (1.0 + np.exp(-rew[:, 0].astype(np.float64)))
     assert_close(D.predict_prob(x).numpy()[:, 0], s_ref, rtol=1e-4, atol=1e-6, what="sigmoid(D(x))")
     s0 = D.predict_prob_single_step(x[0, :11], x[0, 11:14], x[0, 14:])
+    # the reference's own two-argument form on row batches: an [n, 1] tensor (a2c/algo/gail.py:212-217)
+    two = D.predict_prob_single_step(x[:, :11], x[:, 11:])
+    assert tuple(two.shape) == (x.shape[0], 1) and abs(float(two[0, 0]) - s0) < 1e-7
+    with pytest.raises(NotImplementedError):
+        D.compute_grad_pen_combined(x, x)
     assert isinstance(s0, float) and s0 == pytest.approx(float(s_ref[0]), rel=1e-4)
 
 
