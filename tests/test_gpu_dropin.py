@@ -113,3 +113,68 @@ def test_discriminator_epochs_upload_obs_feat_once(sg):
     assert up1 == feat_bytes + mask_bytes, (up1, feat_bytes, mask_bytes)
     assert up2 == 4 * feat_bytes + mask_bytes
     assert l1 == l2 and np.array_equal(r1, r2) and np.array_equal(p1, p2), "tracking what changed must not change any result"
+
+
+def test_literal_main_sequence_equals_the_resident_learner(sg):
+    """The unchanged main's own call sequence on HOST tensors (a2c/main_gail_dyn_ppo.py:239-304 -- what bench.py's `dropin.literal_main`
+    times: gail_epoch x update_gail_dyn, T x [predict_reward_combined + host ret_rms.update + clip], compute_returns, agent.update,
+    after_update) against GailDynLearner.update() on a device-resident twin (fused on-device relabel, nothing uploaded): same
+    seeds, same rollout, two updates.  The discriminator sees identical rows in both, so its weights must be EQUAL; rewards,
+    returns and the policy agree at the float32 tolerance (the relabel's running statistics are float64 on the host in one and
+    on the device in the other)."""
+    import bench
+    import torch
+    from simgan_amd import _lib
+    from simgan_amd.driver import alive_bonus_offset
+    from simgan_amd.utils import RunningMeanStd
+    w = dict(kind="split", T=16, N=32, O=14, A=7, F=25, H=100, feet=1, Hd=100, E_p=2, M=4, E_d=2, B=128, Ne=512, clip=0.2)
+    T, N = w["T"], w["N"]
+    ctx = _lib.Context.default()
+
+    def build():
+        pol, disc, agent, ro, loader, expert, learner = bench.build_problem(sg, w, seed=5)
+        _lib.check(ctx.lib.sg_rollout_fill_synthetic(ro.h, pol.h, 77, 0.03))
+        return pol, disc, agent, ro, loader, learner
+
+    # (a) resident learner
+    pol_r, disc_r, agent_r, ro_r, loader_r, learner_r = build()
+    outs_r = [dict(learner_r.update().resolve()) for _ in range(2)]
+    ro_r.sync_from_device()
+    # (b) the literal sequence on host tensors
+    pol, disc, agent, ro, loader, _ = build()
+    ro.sync_from_device()
+    ro.device_resident = False
+    ret_rms = RunningMeanStd(shape=())
+    outs = []
+    for _ in range(2):
+        with torch.no_grad():
+            next_value = pol.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()
+        for _e in range(w["E_d"]):
+            gail_loss, gail_loss_e, gail_loss_p = disc.update_gail_dyn(loader, ro)
+        num_of_dones = float((1.0 - ro.masks).sum().cpu().numpy())
+        r_sa = alive_bonus_offset(num_of_dones, T, N, 500.0)
+        for step in range(T):
+            ro.rewards[step], returns = disc.predict_reward_combined(ro.obs_feat[step + 1], bench.GAMMA, ro.masks[step], offset=-r_sa)
+            ret_rms.update(returns.view(-1).cpu().numpy())
+            rews = ro.rewards[step].view(-1).cpu().numpy()
+            rews = np.clip(rews / np.sqrt(ret_rms.var + 1e-7), -10.0, 10.0)
+            ro.rewards[step] = torch.Tensor(rews).view(-1, 1)
+        ro.compute_returns(next_value, True, bench.GAMMA, bench.LAM, True)
+        value_loss, action_loss, dist_entropy = agent.update(ro)
+        rewards_after, returns_after = ro.rewards.numpy().copy(), ro.returns.numpy().copy()
+        ro.after_update()
+        outs.append(dict(gail_loss=gail_loss, gail_loss_e=gail_loss_e, gail_loss_p=gail_loss_p, value_loss=value_loss,
+                         action_loss=action_loss, dist_entropy=dist_entropy, r_sa=r_sa))
+    assert np.array_equal(disc.get_flat_params(), disc_r.get_flat_params()), "the discriminator saw the same rows in both modes"
+    for a_, b_ in zip(outs, outs_r):
+        for k in ("gail_loss", "gail_loss_e", "gail_loss_p"):
+            assert a_[k] == b_[k], (k, a_[k], b_[k])
+        assert a_["r_sa"] == pytest.approx(b_["r_sa"], rel=1e-12)
+        assert_close([a_["value_loss"], a_["action_loss"], a_["dist_entropy"]], [b_["value_loss"], b_["action_loss"], b_["dist_entropy"]],
+                     rtol=1e-4, atol=2e-5, what="PPO losses, literal main vs resident learner")
+    assert_close(rewards_after, ro_r.rewards.numpy(), rtol=1e-4, atol=1e-5, what="relabelled rewards of the second update")
+    assert_close(returns_after[:T], ro_r.returns.numpy()[:T], rtol=1e-4, atol=1e-5, what="GAE returns of the second update")
+    assert_close(ret_rms.get_state(), learner_r.ret_rms.get_state(), rtol=1e-5, what="ret_rms after two updates")
+    p_a, p_b = pol.get_flat_params(), pol_r.get_flat_params()
+    move = np.linalg.norm(p_a.astype(np.float64) - build()[0].get_flat_params())
+    assert np.linalg.norm(p_a.astype(np.float64) - p_b) <= 2e-2 * move, "policies of the two modes drifted apart"
