@@ -447,6 +447,57 @@ def dropin_leg(sg, _lib, ctx, w, updates=5):
     return res
 
 
+KEEPER_CODE = r"""
+import json, os, sys
+fd, last, final = int(sys.argv[1]), None, False
+for line in sys.stdin:                      # until the bench process closes the pipe -- or dies
+    line = line.rstrip("\n")
+    if line[:2] == "F ":
+        last, final = line[2:], True
+    elif line[:2] == "S ":
+        last = line[2:]
+if last is not None:
+    if not final:
+        try:
+            d = json.loads(last)
+            d["error_after_headline"] = ("the bench process ended before it printed its line (killed or crashed in a leg that runs after the "
+                                         "headline measurement); this is the line as it stood")
+            last = json.dumps(d)
+        except Exception:
+            pass
+    os.write(fd, (last + "\n").encode())
+"""
+
+
+class LineKeeper(object):
+    """From the moment the headline measurement is complete, the ONE result line is printed by a small helper process that
+    holds the latest complete version of it: rank 0 hands it every update of the line and, at the end, the final one.  If the
+    bench process is killed or aborts in a later leg (a GPU fault in the first multi-GPU run of the peer mesh, an
+    out-of-memory kill during the CPU baseline), the helper sees the pipe close and prints the line as it stood, marked
+    `error_after_headline` -- the measured headline is never lost with the process.  The helper sits in a session of its own
+    (a launcher that kills the ranks' process group does not take it along) and never touches the GPU."""
+
+    def __init__(self, result_fd):
+        self.p = subprocess.Popen([sys.executable, "-c", KEEPER_CODE, str(result_fd)], stdin=subprocess.PIPE, pass_fds=(result_fd,),
+                                  start_new_session=True, text=True)
+
+    def store(self, obj):
+        try:
+            self.p.stdin.write("S " + json.dumps(obj) + "\n")
+            self.p.stdin.flush()
+        except (OSError, ValueError):
+            pass
+
+    def finish(self, obj):
+        """True when the helper printed the final line."""
+        try:
+            self.p.stdin.write("F " + json.dumps(obj) + "\n")
+            self.p.stdin.close()
+            return self.p.wait(timeout=20) == 0
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            return False
+
+
 class Watchdog(object):
     """First-run insurance for the N-GPU launch: whatever happens -- a hung ncclCommInitRank, a first collective that never
     completes, a peer that dies and takes the launcher's SIGTERM with it -- rank 0 still prints ONE JSON line, carrying
@@ -577,6 +628,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the brief runs of BASELINE.json's other configurations")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (the unchanged main's call sequence on host tensors)")
+    ap.add_argument("--no-line-keeper", action="store_true", help="print the line from this process only (no helper process holding it after the headline)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline measurement (+ cpu baseline unless --no-cpu-baseline)")
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
     ap.add_argument("--no-other-allreduce", action="store_true", help="N > 1: skip timing the other form of the per-step all-reduce (peer mesh / base communicator)")
@@ -596,7 +648,12 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    keeper = {"k": None}
+
     def emit(obj):
+        k, keeper["k"] = keeper["k"], None
+        if k is not None and k.finish(obj):
+            return
         os.write(result_fd, (json.dumps(obj) + "\n").encode())
 
     w = WORKLOADS[args.workload]
@@ -774,6 +831,22 @@ def main():
     if world > 1 and rank == 0:
         out["replica_check"] = ({"ok": replica.get("ok"), "weights_sha256_rank0": replica["digests"][0][:16], "ranks": world}
                                 if replica["checked"] else "skipped (--no-dp-check)")
+    # The headline is measured.  Everything below is reported beside it; from here on the line is in the keeping of a helper
+    # process (LineKeeper), so that whatever happens to THIS process in a later leg, the line still comes out.
+    def keep():
+        if keeper["k"] is not None:
+            keeper["k"].store(out)
+
+    if rank == 0 and not args.no_line_keeper:
+        try:
+            keeper["k"] = LineKeeper(result_fd)
+            keep()
+        except OSError:
+            keeper["k"] = None
+    if os.environ.get("SG_BENCH_DIE_AFTER_HEADLINE") == str(rank):   # test hook: the process is killed outright in a later leg
+        import signal
+        time.sleep(0.5)
+        os.kill(os.getpid(), signal.SIGKILL)
     dog.stage("other discriminator mode / cpu baseline / output", 1e9)   # the other-mode timing has its own watchdog below
     if (world > 1 or force_alt) and w["E_d"] and not args.no_other_disc_mode:
         import threading
@@ -802,6 +875,7 @@ def main():
         ctx.set_disc_dp(not ctx.disc_sharded)
         if rank == 0:
             out["comm"]["disc_other_mode"] = alt
+            keep()
     # N > 1: the OTHER form of the per-step all-reduce -- the peer mesh when the headline ran on the base communicator (RCCL),
     # the base communicator when SG_COMM_PEER=1 -- on the same communicator, toggled collectively (sg_ctx_comm_set_peer), so
     # that the first multi-GPU run comes back with both timed.  Own watchdog; a failure leaves an `error` entry.
@@ -842,6 +916,7 @@ def main():
         dog.stage("all-reduce forms done / cpu baseline / output", 1e9)
         if rank == 0:
             out["comm"][field] = leg
+            keep()
     if world == 1 and not force_alt and not args.headline_only:
         # Everything below is reported BESIDE `value`, never as it; the headline is complete.  A leg that fails or runs out
         # of its budget leaves an `error` entry: the line is not lost (the stage watchdog prints what it has and ends the run).
@@ -857,12 +932,14 @@ def main():
                     out["other_workloads"][other_name] = brief_workload(sg, _lib, ctx, other_name)
                 except Exception as exc:
                     out["other_workloads"][other_name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                keep()
         if w["E_d"] and not args.no_dropin:
             dog.stage("drop-in legs (host tensors through the alias classes)", 180.0)
             try:
                 out["dropin"] = dropin_leg(sg, _lib, ctx, w)
             except Exception as exc:
                 out["dropin"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            keep()
         dog.stage("cpu baseline / output", 1e9)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -600,3 +600,27 @@ def test_bench_replica_check_is_reported(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["replica_check"]["ok"] is True and out["replica_check"]["ranks"] == 2, out["replica_check"]
+
+
+def test_bench_line_survives_the_death_of_the_bench_process_after_the_headline():
+    """After the headline measurement the line is in the keeping of a helper process (bench.LineKeeper): the bench process is
+    killed outright (SIGKILL, the hook stands in for a GPU fault or an out-of-memory kill in a later leg) and ONE line still comes
+    out, with the measured value and `error_after_headline`."""
+    import json
+    import subprocess
+    env = dict(os.environ, SG_BENCH_DIE_AFTER_HEADLINE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "refine", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, "the hook kills the process"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (lines, r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and "error_after_headline" in out, out
+    # ... and without the hook the same command prints the same one line, without the mark
+    env.pop("SG_BENCH_DIE_AFTER_HEADLINE")
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "refine", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and "error_after_headline" not in json.loads(lines[0]), (r.returncode, lines, r.stderr[-2000:])
