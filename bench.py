@@ -837,6 +837,8 @@ def main():
         if keeper["k"] is not None:
             keeper["k"].store(out)
 
+    if rank == 0:
+        dog.final = out      # a watchdog time-out or the launcher's SIGTERM from here on prints THIS line (with what went wrong), not an empty one
     if rank == 0 and not args.no_line_keeper:
         try:
             keeper["k"] = LineKeeper(result_fd)
@@ -920,7 +922,6 @@ def main():
     if world == 1 and not force_alt and not args.headline_only:
         # Everything below is reported BESIDE `value`, never as it; the headline is complete.  A leg that fails or runs out
         # of its budget leaves an `error` entry: the line is not lost (the stage watchdog prints what it has and ends the run).
-        dog.final = out
         import gc
         del learner, agent, disc, ro, pol, loader
         gc.collect()    # the handles are freed HERE (hipFree waits for the device), not by a collection inside a later timed loop

@@ -624,3 +624,19 @@ def test_bench_line_survives_the_death_of_the_bench_process_after_the_headline()
                        capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1 and "error_after_headline" not in json.loads(lines[0]), (r.returncode, lines, r.stderr[-2000:])
+
+
+def test_bench_line_survives_a_peer_rank_dying_after_the_headline():
+    """N > 1: rank 1 is killed after the headline (in what would be the other-mode / peer-mesh legs); the launcher ends rank 0,
+    whose watchdog prints the line it had -- the measured value with `error_after_headline`, not an empty line."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SG_LOOPBACK_TIMEOUT_S="60", SG_BENCH_DIE_AFTER_HEADLINE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--loopback", "--workload", "refine", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (lines, r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "error_after_headline" in out, out
