@@ -258,7 +258,25 @@ def load_tdoc(workload):
         return {}
 
 
-def kernel_report(w, work, prof, tdoc):
+def load_cdoc(workload):
+    """The committed SQ / TCC counter summary of `workload` (tools/profile_counters.sh -> tools/make_counters.py ->
+    profiles/counters.json), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+            return json.load(f)["workloads"].get(workload, {})
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def load_ctag():
+    try:
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+            return json.load(f).get("tag")
+    except (OSError, ValueError):
+        return None
+
+
+def kernel_report(w, work, prof, tdoc, cdoc=None):
     """Per-kernel roofline entries from the HIP-event pass `prof` (slot -> (total ms, launches)) and the dominant kernel:
     the discriminator step -- one launch (k_disc_step4) where the library runs it so, else its chain kernel -- or, without
     a discriminator, the PPO backward."""
@@ -266,6 +284,12 @@ def kernel_report(w, work, prof, tdoc):
         try:
             return tdoc["kernels"][kname][key]
         except KeyError:
+            return None
+
+    def ck(kname, key):
+        try:
+            return cdoc["kernels"][kname]["derived"][key]
+        except (KeyError, TypeError):
             return None
 
     kmap = {}
@@ -283,6 +307,9 @@ def kernel_report(w, work, prof, tdoc):
                        "algorithmic_bytes": kbytes, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
                        "rocprof_avg_us": pus, "frac_profiled": round(ach / peak * (avg_s * 1e6) / pus, 5) if pus else None,
                        "traffic": tk(kname, "hbm_bytes_per_launch")}
+        if bound == "mfma":
+            kmap[kname].update({"mfma_busy": ck(kname, "mfma_busy"), "mfma_busy_resident": ck(kname, "mfma_busy_resident"),
+                                "wave_wait": ck(kname, "wave_wait"), "l2_hit": ck(kname, "l2_hit")})
     one_launch = bool(w["E_d"]) and prof["disc_step"][1] > 0
     slot = ("disc_step" if one_launch else "disc_chain") if w["E_d"] else "ppo_bwd"
     kname = work["kernels"][slot][0]
@@ -294,7 +321,9 @@ def kernel_report(w, work, prof, tdoc):
     dom = {"kernel": kname, "flops": flops, "avg_s": avg_s, "launches": n_, "achieved": achieved,
            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "rocprof_avg_us": pus,
            "frac_profiled": (flops / (pus * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if pus else None,
-           "traffic": tk(kname, "hbm_bytes_per_launch")}
+           "traffic": tk(kname, "hbm_bytes_per_launch"),
+           "counters": {k: ck(kname, k) for k in ("mfma_busy", "mfma_busy_resident", "mfma_busy_grbm", "mfma_flops", "wave_wait", "wave_issue_stall",
+                                                  "wave_active", "lds_conflict", "l2_hit")}}
     return kmap, dom
 
 
@@ -343,7 +372,7 @@ def brief_workload(sg, _lib, ctx, name, steps=10, warmup=5):
     wall, per, last = run_updates(ctx, learner, steps)
     prof = profile_pass(ctx, learner)
     work = algorithmic_work(w, 1)
-    kmap, dom = kernel_report(w, work, prof, load_tdoc(name))
+    kmap, dom = kernel_report(w, work, prof, load_tdoc(name), load_cdoc(name))
     ms = 1e3 * wall / steps
     out = {"metric": "env-steps/sec of GAIL-dyn PPO update" if w["E_d"] else "env-steps/sec of PPO update (a2c/main.py)",
            "value": round(w["T"] * w["N"] * steps / wall, 1), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
@@ -352,7 +381,8 @@ def brief_workload(sg, _lib, ctx, name, steps=10, warmup=5):
            "shape": f"T={w['T']} N={w['N']} obs={w['O']} act={w['A']} D-in={w['F'] if w['E_d'] else '-'} policy={w['kind']} h{w['H']} num_mini_batch={w['M']}",
            "roofline": {"kernel": dom["kernel"], "bound": "mfma", "avg_launch_us": round(dom["avg_s"] * 1e6, 2), "launches": dom["launches"],
                         "achieved": round(dom["achieved"], 3), "unit": "TFLOP/s", "frac": round(dom["frac"], 5),
-                        "frac_profiled": round(dom["frac_profiled"], 5) if dom["frac_profiled"] else None},
+                        "frac_profiled": round(dom["frac_profiled"], 5) if dom["frac_profiled"] else None,
+                        "mfma_busy": dom["counters"]["mfma_busy"]},
            "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items() if v[1]},
            "last_losses": dict(last)}
     del learner, agent, disc, ro, pol, loader, last
@@ -445,6 +475,86 @@ def dropin_leg(sg, _lib, ctx, w, updates=5):
     del learner, agent, disc, ro, pol, loader
     gc.collect()
     return res
+
+
+def _sel(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full, full_path=None):
+    """The ONE stdout line: every key of the driver's contract plus the numbers a reader of a 2 KB tail needs -- the
+    dominant kernel's roofline (both clocks, counter traffic, MFMA-busy from the SQ counters), the CPU baseline, and one
+    {ms, env_steps_s, frac} triple per other BASELINE.json configuration and for the unchanged main's call sequence.
+    Everything else (per-kernel tables, spreads, samples' descriptions, the comm legs' per-rank lists) is in the FULL record,
+    written to `full_path` (named in the line) and to stderr."""
+    c = _sel(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "error", "stage", "elapsed_s", "error_after_headline", "ranks", "us_per_optimizer_step"))
+    if full.get("n_gpus", 1) > 1 and "per_rank_ms_per_step" in full:
+        c["per_rank_ms_per_step"] = full["per_rank_ms_per_step"]
+    c.setdefault("vs_baseline", None)
+    c.setdefault("value", full.get("value"))
+    cfg = dict(full.get("config", {}))
+    if len(str(cfg.get("workload", ""))) > 120:       # the driver's record keeps 120 characters of a string
+        cfg["workload"] = cfg["workload"][:117] + "..."
+    c["config"] = cfg
+    r = full.get("roofline")
+    if r:
+        c["roofline"] = _sel(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_profiled", "mfma_busy", "mfma_busy_resident_cus", "traffic",
+                                 "avg_launch_us", "traffic_stale", "counters_stale"))
+        c["roofline"]["traffic"] = r.get("traffic")
+        c["roofline"]["lib_sha16"] = (r.get("lib_sha256") or "")[:16]
+        c["roofline"]["update_frac_mfma"] = r.get("whole_update", {}).get("frac_mfma")
+        c["roofline"]["update_frac_hbm"] = r.get("whole_update", {}).get("frac_hbm")
+        kk = {name[2:]: [k.get("avg_us"), k.get("frac"), k.get("mfma_busy")] for name, k in (r.get("kernels") or {}).items()
+              if name != r.get("kernel") and k.get("bound") == "mfma"}
+        if kk:
+            c["roofline"]["others_us_frac_busy"] = kk
+    if "last_losses" in full and full.get("n_gpus", 1) > 1:
+        c["last_losses"] = {k: (round(v, 6) if full.get("n_gpus", 1) > 1 else float(f"{v:.4g}")) for k, v in full["last_losses"].items()}
+    ow = full.get("other_workloads")
+    if ow:
+        c["other_workloads_ms_envsteps_frac_busy"] = {n: (str(v["error"])[:80] if "error" in v else
+                                                      [v.get("ms_per_step"), round(v.get("value", 0.0)), v.get("roofline", {}).get("frac"), v.get("roofline", {}).get("mfma_busy")]) for n, v in ow.items()}
+        cfg["others_ms"] = " ".join(f"{n}={v.get('ms_per_step', 'err')}" for n, v in ow.items())
+    dr = full.get("dropin")
+    if dr:
+        c["dropin_ms"] = _sel(dr, ("error",)) or {k: dr.get(k, {}).get("ms_per_step") for k in ("literal_main", "learner_host_buffers")}
+        if "literal_main" in dr:
+            cfg["literal_main_ms"] = dr["literal_main"].get("ms_per_step")
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _sel(cb, ("value", "unit", "cores", "kind", "port_value", "host_cores_available"))
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:72]
+        if isinstance(cb.get("all_cores"), dict):
+            c["cpu_baseline"]["all_cores_value"] = cb["all_cores"].get("value")
+            c["cpu_baseline"]["all_cores_threads"] = cb["all_cores"].get("cores")
+    cm = full.get("comm")
+    if cm:
+        c["comm"] = _sel(cm, ("kind", "nranks_reported_by_rccl", "disc_mode", "peer_allreduce", "allreduce_us", "allreduce_count_per_update", "allreduce_form"))
+        for leg in ("disc_other_mode", "peer", "base"):
+            if leg in cm:
+                c["comm"][leg] = _sel(cm[leg], ("mode", "form", "value", "ms_per_step", "allreduce_us", "error", "restore_error"))
+    if "replica_check" in full:
+        c["replica_check"] = full["replica_check"]
+    if full_path:
+        c["full_record"] = full_path
+    return c
+
+
+def write_full(full, workload, world):
+    """The full record beside the compact line: gpurun_out/bench_full_<workload>_n<N>.json under the repository (merged back
+    by gpurun), else the temp directory.  Returns the path written (None when nothing could be written)."""
+    import tempfile
+    for d in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, f"bench_full_{workload}_n{world}.json")
+            with open(path, "w") as f:
+                json.dump(full, f)
+            return os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))) if d.endswith("gpurun_out") else path
+        except OSError:
+            continue
+    return None
 
 
 KEEPER_CODE = r"""
@@ -629,6 +739,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the brief runs of BASELINE.json's other configurations")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (the unchanged main's call sequence on host tensors)")
     ap.add_argument("--no-line-keeper", action="store_true", help="print the line from this process only (no helper process holding it after the headline)")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL record on stdout instead of the compact line (the default writes it to gpurun_out/bench_full_<workload>_n<N>.json and stderr)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline measurement (+ cpu baseline unless --no-cpu-baseline)")
     ap.add_argument("--no-other-disc-mode", action="store_true", help="N > 1: skip timing the non-default discriminator mode")
     ap.add_argument("--no-other-allreduce", action="store_true", help="N > 1: skip timing the other form of the per-step all-reduce (peer mesh / base communicator)")
@@ -650,11 +761,21 @@ def main():
 
     keeper = {"k": None}
 
+    def shape(obj):
+        """stdout gets the compact line (--full-line: the whole record); the whole record goes to a file and to stderr."""
+        if args.full_line:
+            return obj
+        path = write_full(obj, args.workload, int(os.environ.get("WORLD_SIZE", "1")))
+        return compact_line(obj, path)
+
     def emit(obj):
         k, keeper["k"] = keeper["k"], None
-        if k is not None and k.finish(obj):
+        line = shape(obj)
+        if not args.full_line:
+            sys.stderr.write("[bench] full record: " + json.dumps(obj) + "\n")
+        if k is not None and k.finish(line):
             return
-        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
 
     w = WORKLOADS[args.workload]
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -758,7 +879,8 @@ def main():
         tdoc = load_tdoc(args.workload)
         traffic_sha = tdoc.get("lib_sha256")
         traffic_stale = bool(tdoc) and traffic_sha != lib_sha
-        kmap, dom = kernel_report(w, work, prof, tdoc)
+        cdoc = load_cdoc(args.workload)
+        kmap, dom = kernel_report(w, work, prof, tdoc, cdoc)
         dom_kernel, dom_flops, dg_avg_s, dg_n, achieved, traffic = dom["kernel"], dom["flops"], dom["avg_s"], dom["launches"], dom["achieved"], dom["traffic"]
 
         def profiled_us(kname):
@@ -792,6 +914,13 @@ def main():
                          "rocprof_avg_launch_us": profiled_us(dom_kernel),
                          "rocprof_source": tdoc.get("kernel_trace", "no kernel trace of this workload committed"),
                          "lib_sha256": lib_sha, "traffic_lib_sha256": traffic_sha, "traffic_stale": traffic_stale,
+                         # SQ counters of the committed counter passes (tools/profile_counters.sh -> profiles/counters.json): the matrix
+                         # pipes' busy cycles over (the cycles the kernel keeps a shader engine busy x the chip's 1024 SIMDs), and the
+                         # same over the CU-cycles in which a CU holds a wave of the kernel
+                         "mfma_busy": dom["counters"]["mfma_busy"], "mfma_busy_resident_cus": dom["counters"]["mfma_busy_resident"],
+                         "counters": dom["counters"], "counters_lib_sha256": cdoc.get("lib_sha256"),
+                         "counters_stale": bool(cdoc) and cdoc.get("lib_sha256") != lib_sha,
+                         "counters_source": f"profiles/counters.json (tag {load_ctag()}, passes {cdoc.get('passes')})" if cdoc else "no counter passes of this workload committed",
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE and WRITE_SIZE (separate passes) with the per-access-width calibration named in profiles/traffic.json; " + str(tdoc.get("source", "no profile of this workload committed")),
                          "avg_launch_us": round(dg_avg_s * 1e6, 2), "launches": dg_n,
                          "kernels": kmap,
@@ -835,7 +964,7 @@ def main():
     # process (LineKeeper), so that whatever happens to THIS process in a later leg, the line still comes out.
     def keep():
         if keeper["k"] is not None:
-            keeper["k"].store(out)
+            keeper["k"].store(shape(out))
 
     if rank == 0:
         dog.final = out      # a watchdog time-out or the launcher's SIGTERM from here on prints THIS line (with what went wrong), not an empty one

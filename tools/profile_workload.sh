@@ -35,6 +35,7 @@ cd $root
 # (the north-star line is the driver's own command: it also carries the other workloads' brief runs and the drop-in legs)
 extra=$([ "$wl" = "northstar" ] && echo "" || echo "--headline-only")
 timeout 900 python bench.py --workload $wl --cpu-seconds 8 $extra > $out/${tag}_${wl}_bench.json 2> $out/${tag}_${wl}_bench.err
+[ -f $out/bench_full_${wl}_n1.json ] && mv $out/bench_full_${wl}_n1.json $out/${tag}_${wl}_bench_full.json   # the full record beside the compact line
 head -12 $out/${tag}_${wl}_kernel_trace.txt
 head -6 $out/${tag}_${wl}_pmc_fetch_size.txt
 head -6 $out/${tag}_${wl}_pmc_write_size.txt
