@@ -238,6 +238,13 @@ SG_API int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma
 /* Discriminator.predict_prob_single_step(s, a, s_n) a2c/algo/gail.py:212-217: prob[n] = sigmoid(D(x)) on the
  * caller-concatenated rows x[n,F]. */
 SG_API int sg_disc_predict_prob(sg_disc *d, const float *x, int n, float *prob);
+/* Discriminator.compute_grad_pen_combined(expert_combined, policy_combined, lambda_) a2c/algo/gail.py:67-89 (and
+ * compute_grad_pen :53-65 on caller-concatenated rows), the VALUE only: pen[i] = (||dD/dx(alpha_i e_i + (1 - alpha_i) p_i)||_2 - 1)^2
+ * for the n row pairs expert_rows[n,F] / policy_rows[n,F]; the reference's scalar is lambda_ * mean(pen).  alpha[n] is the
+ * reference's torch.rand(n, 1) draw (:72), NULL -> the library's generator with `seed`.  The differentiable term the reference adds
+ * to its loss is formed inside the update kernels (sg_disc_update_gail_dyn / _rows); this call changes no state. */
+SG_API int sg_disc_grad_pen(sg_disc *d, const float *expert_rows, const float *policy_rows, const float *alpha, int n,
+                     uint64_t seed, float *pen);
 /* The draws the last update epoch consumed: expert_perm[n_expert], policy_perm[n_policy_rows], alpha[n_alpha]
  * (injected or library-drawn); each pointer may be NULL, each count must match the epoch's size (returned in
  * counts3 = {n_expert, n_policy_rows, n_alpha} when counts3 != NULL). */

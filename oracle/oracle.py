@@ -306,6 +306,14 @@ def disc_grad_rows(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda
     return G, np.array(list(sums))
 
 
+def disc_grad_pen(F, Hd, params, expert_rows, policy_rows, alpha, lambda_=10.0):
+    """Discriminator.compute_grad_pen_combined a2c/algo/gail.py:67-89, the value: lambda * mean((||dD/dx(mix)|| - 1)^2)
+    (orc_disc_grad_rows' third sum; its gradient output is discarded)."""
+    n = np.asarray(expert_rows).shape[0]
+    _, sums = disc_grad_rows(F, Hd, params, expert_rows, policy_rows, alpha, 1.0 / n, lambda_)
+    return np.float32(lambda_) * np.float32(sums[2] / n)
+
+
 def adam_step(params, G, adam, lr, eps):
     lib().orc_adam_step(_fp(params), _fp(G), _fp(adam.m), _fp(adam.v), C.byref(adam.t),
                         C.c_int64(params.size), C.c_float(lr), C.c_float(eps))

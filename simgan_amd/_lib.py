@@ -91,6 +91,7 @@ PROTOTYPES = {
                                       C.c_int64, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
     "sg_disc_predict_prob": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
+    "sg_disc_grad_pen": (C.c_int, [H, c_float_p, c_float_p, c_float_p, C.c_int, C.c_uint64, c_float_p]),
     "sg_disc_last_draws": (C.c_int, [H, c_i64_p, c_i64_p, c_float_p, c_i64_p]),
     "sg_disc_reset_returns": (C.c_int, [H]),
     "sg_disc_get_returns": (C.c_int, [H, c_float_p, C.c_int, c_int_p]),
@@ -228,13 +229,27 @@ class _PinnedBlock(object):
             pass
 
 
+_PINNED_WARNED = False
+
+
 def pinned_array(shape, fill=0.0):
     """float32 numpy array of `shape` in page-locked host memory (include/simgan_hip.h: sg_host_alloc).  The allocation
     lives as long as any view of the array (numpy / torch.from_numpy keep the owner alive through `.base`)."""
     n = int(np.prod(shape)) * 4
     if n == 0:
         return np.full(shape, fill, np.float32)
-    blk = _PinnedBlock(n)
+    try:
+        blk = _PinnedBlock(n)
+    except SimganHipError as exc:
+        # RLIMIT_MEMLOCK / the container's pinned-memory limit, or a rollout too large to pin: pageable memory works everywhere
+        # the pinned buffer does (the upload path stages it), only slower
+        global _PINNED_WARNED
+        if not _PINNED_WARNED:
+            _PINNED_WARNED = True
+            import warnings
+            warnings.warn(f"simgan_amd: page-locked host allocation of {n} bytes failed ({exc}); the rollout's host tensors fall back to "
+                          "pageable memory (uploads are staged and slower)", RuntimeWarning, stacklevel=3)
+        return np.full(shape, fill, np.float32)
     buf = (C.c_char * n).from_address(blk.ptr)
     buf._owner = blk
     a = np.frombuffer(buf, dtype=np.float32).reshape(shape)

@@ -238,13 +238,27 @@ class Discriminator(object):
         _lib.check(self.lib.sg_disc_predict_prob(self.h, _lib.fptr(x), 1, _lib.fptr(out)))
         return float(out[0])
 
-    def compute_grad_pen(self, *a, **k):
-        """a2c/algo/gail.py:53-89: in the reference a differentiable term that `update` / `update_gail_dyn` add to their loss
-        before `.backward()` -- nothing else calls it.  Here the penalty AND its double backward are formed inside the update
-        step's kernels (k_disc_step4 / k_disc_chain), so there is no stand-alone differentiable penalty to hand out."""
-        raise NotImplementedError("compute_grad_pen[_combined] is fused into update() / update_gail_dyn() (a2c/algo/gail.py:133,179 are its only callers)")
+    def compute_grad_pen(self, expert_state, expert_action, policy_state, policy_action, lambda_=10., alpha=None):
+        """a2c/algo/gail.py:53-65: the penalty on (state | action) rows."""
+        cat = lambda x, y: np.concatenate([_lib.as_f32(x).reshape(len(x), -1), _lib.as_f32(y).reshape(len(y), -1)], axis=1)  # noqa: E731
+        return self.compute_grad_pen_combined(cat(expert_state, expert_action), cat(policy_state, policy_action), lambda_, alpha=alpha)
 
-    compute_grad_pen_combined = compute_grad_pen
+    def compute_grad_pen_combined(self, expert_combined, policy_combined, lambda_=10., alpha=None):
+        """a2c/algo/gail.py:67-89 -> lambda_ * mean((||dD/dx(alpha e + (1 - alpha) p)||_2 - 1)^2) as a 0-dim host tensor: the
+        VALUE of the term.  In the reference it is a differentiable tensor that `update` / `update_gail_dyn` add to their loss
+        before `.backward()` (:133, :179, its only callers); here the penalty and its double backward are formed inside the
+        update step's kernels, so the returned value carries no graph.  `alpha` injects the reference's torch.rand(n, 1)
+        draw (:72); default: the library's generator."""
+        e = np.ascontiguousarray(_lib.as_f32(expert_combined).reshape(-1, self.input_dim))
+        p = np.ascontiguousarray(_lib.as_f32(policy_combined).reshape(-1, self.input_dim))
+        assert e.shape == p.shape, (e.shape, p.shape)        # alpha.expand_as / the elementwise mix would raise in the reference
+        al = None if alpha is None else np.ascontiguousarray(_lib.as_f32(alpha).reshape(-1))
+        assert al is None or al.size == e.shape[0], "one alpha per row pair"
+        pen = np.empty(e.shape[0], np.float32)
+        self._calls += 1
+        _lib.check(self.lib.sg_disc_grad_pen(self.h, _lib.fptr(e), _lib.fptr(p), None if al is None else _lib.fptr(al), e.shape[0],
+                                             (self.seed + self._calls) & (2 ** 64 - 1), _lib.fptr(pen)))
+        return to_host_tensor(np.asarray(np.float32(lambda_) * pen.mean(dtype=np.float32), np.float32))
 
     def predict_prob(self, d_in):
         """Batched form of predict_prob_single_step: sigmoid(D(x)) for rows x [n, F] -> [n, 1]."""

@@ -107,6 +107,7 @@ struct SgPeer {
     void* own = nullptr;                     // this rank's allocation (slots | flags | ctrl)
     void* mapped[SG_PEER_MAX_WORLD] = {nullptr};   // hipIpcOpenMemHandle results (other processes' buffers)
     uint64_t launches = 0;
+    uint32_t generation = 0;                 // process-wide, never 0, never reused: keys the hipGraphs that captured this mesh's pointers
 };
 
 struct SgComm {
@@ -443,6 +444,8 @@ static int peer_setup(sg_ctx* ctx) {
     const size_t flag_b = sizeof(unsigned) * 2 * (size_t)W * SG_PEER_MAX_BLOCKS * SG_PEER_FLAG_STRIDE;
     const size_t total = slot_b + flag_b + 256;
     SgPeer* p = new SgPeer();
+    static std::atomic<uint32_t> next_generation{1};
+    p->generation = next_generation.fetch_add(1);
     int rc = 0;            // this rank's own outcome; the error text of the first local failure is kept
     char why[512] = "";
     auto fail = [&](int code, const char* fmt, auto... args) {
@@ -538,6 +541,9 @@ static int peer_setup(sg_ctx* ctx) {
 // (sg_results_publish) so that a collective that gave up is reported at the next read of the losses.
 unsigned* sg_comm_peer_err_word(sg_ctx* ctx) { return (ctx->comm && ctx->comm->peer) ? ctx->comm->peer->dev.ctrl + 2 : nullptr; }
 bool sg_comm_peer_on(const sg_ctx* ctx) { return ctx->comm && ctx->comm->peer; }
+// The captured update graphs hold k_peer_allreduce nodes with THIS mesh's slot and flag pointers by value: a mesh that was torn
+// down and set up again (sg_ctx_comm_set_peer(0) then (1)) must not match the old graph's key.
+uint32_t sg_comm_peer_generation(const sg_ctx* ctx) { return (ctx->comm && ctx->comm->peer) ? ctx->comm->peer->generation : 0u; }
 
 // Collective: every rank of the communicator calls it with the same `enable`.  1: build the mesh over the base communicator
 // (what SG_COMM_PEER=1 does at sg_ctx_comm_init); 0: drop it, the small all-reduces go back to the base communicator.

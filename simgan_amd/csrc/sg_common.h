@@ -210,6 +210,7 @@ struct sg_policy {
 #define SG_PAIR_ERR_WORD 0
 unsigned* sg_comm_peer_err_word(struct sg_ctx* ctx);   // sg_comm.cpp: the peer mesh's sticky time-out word, or NULL
 bool sg_comm_peer_on(const struct sg_ctx* ctx);
+uint32_t sg_comm_peer_generation(const struct sg_ctx* ctx);   // 0: no mesh; else unique to the mesh instance (graph keys)
 unsigned* sg_disc_err_word(struct sg_disc* d);   // sg_disc.hip: k_disc_step4's sticky time-out word (device address)
 uint64_t sg_next_feat_version();   // sg_ctx.cpp: process-wide, monotonic, never 0
 struct sg_rollout {
@@ -252,8 +253,6 @@ struct sg_ppo {
     unsigned* d_pair = nullptr;    // k_ppo_pair: error word
     bool self_wait_failed = false; // a k_ppo_pair hand-off timed out on this object: its later updates run the two-launch step
     bool pair_primed = false;      // the row stacks were cleared for k_ppo_pair's tagged words and no other mode has run since
-    unsigned long long* d_small = nullptr;   // k_ppo_small: the trunks' tagged words [2][2][SG_SMALL_WORDS]
-    bool small_primed = false;     // ... cleared since the step counter was last set (sg_ppo_set_adam)
 };
 
 struct sg_disc {

@@ -1,4 +1,5 @@
 // sg_ctx.cpp -- context, error reporting, scratch arenas, HIP-event profiling slots.
+#include <errno.h>
 #include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
@@ -34,6 +35,7 @@ static std::atomic<int> g_learner_ctx[64];
 // see: processes in another container (their own /dev/shm) -- SG_DISC_FUSED=0 SG_PPO_PAIR=0 remain for that.
 static std::mutex g_lock_m;
 static int g_lock_fd[64];
+static bool g_lock_failed[64];   // the lock could not be taken: exclusivity cannot be established (sg_ctx_exclusive: false)
 static bool g_lock_init = false;
 
 static void device_lock_take(int device) {
@@ -46,14 +48,27 @@ static void device_lock_take(int device) {
     const char* dir = getenv("SG_LOCK_DIR");
     char path[256];
     snprintf(path, sizeof path, "%s/sg_gpu_%s.lock", dir && *dir ? dir : "/dev/shm", bus);
-    const mode_t old = umask(0);
+    // (no umask() games: the mask is process-wide and another thread may be creating files; the mode is widened on the descriptor,
+    // which only the file's creator can and need do)
     const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    umask(old);
-    if (fd < 0) return;      // no lock file (read-only /dev/shm?): other processes stay invisible, as before round 5
+    if (fd >= 0) (void)fchmod(fd, 0666);
     struct flock fl;
     memset(&fl, 0, sizeof fl);
     fl.l_type = F_RDLCK; fl.l_whence = SEEK_SET;
-    if (fcntl(fd, F_SETLK, &fl) != 0) { close(fd); return; }
+    if (fd < 0 || fcntl(fd, F_SETLK, &fl) != 0) {
+        // Without the lock other processes' learners cannot be seen: this process then must not claim the device for itself --
+        // sg_ctx_exclusive answers false and the updates take their multi-launch forms (bit-identical, a few percent slower).
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+            fprintf(stderr, "[simgan_hip] cannot take the per-device lock %s (%s): other processes on this GPU cannot be detected, so the "
+                            "one-launch update forms are off (SG_LOCK_DIR names another directory; SG_LOCK_OPTIONAL=1 keeps them on)\n",
+                    path, strerror(errno));
+        if (fd >= 0) close(fd);
+        const char* opt = getenv("SG_LOCK_OPTIONAL");
+        g_lock_failed[device & 63] = !(opt && opt[0] == '1');
+        return;
+    }
+    g_lock_failed[device & 63] = false;
     g_lock_fd[device & 63] = fd;
 }
 
@@ -66,6 +81,7 @@ static void device_lock_drop(int device) {
 
 static bool device_other_process(int device) {
     std::lock_guard<std::mutex> l(g_lock_m);
+    if (g_lock_init && g_lock_failed[device & 63]) return true;    // unknown: assume somebody is there
     if (!g_lock_init || g_lock_fd[device & 63] < 0) return false;
     struct flock fl;
     memset(&fl, 0, sizeof fl);

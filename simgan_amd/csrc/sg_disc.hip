@@ -94,15 +94,6 @@ static void launch_disc_step4(sg_ctx* ctx, const SgDiscDesc& dd, sg_disc* d, flo
     else SG_STEP4(1, 1);
 #undef SG_STEP4
 }
-// When a weight-gradient wave of k_disc_step4 first asks for the BCE half / the mixup half of its operands, in 10 ns ticks
-// after its workgroup's start (sg_disc_step4.hpp; measured with tools/step4_times.py).  SG_STEP4_TA / SG_STEP4_TB override.
-static void sg_step4_poll_times(const SgDiscDesc& dd, int* ta, int* tb) {
-    const int kf = dd.Fp / 16, kh = dd.Hp / 16;
-    *ta = (kf == 6 && kh == 7) ? 300 : (kf == 2 && kh == 7) ? 240 : 0;
-    *tb = (kf == 6 && kh == 7) ? 370 : (kf == 2 && kh == 7) ? 300 : 0;
-    if (const char* e = getenv("SG_STEP4_TA")) *ta = atoi(e);
-    if (const char* e = getenv("SG_STEP4_TB")) *tb = atoi(e);
-}
 unsigned* sg_disc_err_word(sg_disc* d) { return reinterpret_cast<unsigned*>(d->d_state) + SG_STEP4_ERR_WORD; }
 static void disc_refresh_images(sg_disc* d) {
     hipLaunchKernelGGL(k_disc_images, dim3(32), dim3(256), 0, d->ctx->stream, d->desc, d->d_params, d->d_wT);
@@ -111,6 +102,62 @@ static void disc_refresh_images(sg_disc* d) {
 __global__ void k_fill_alpha(float* alpha, int64_t n, uint64_t seed, uint64_t stream) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) alpha[i] = sg_uniform(seed, stream, (uint64_t)i);
+}
+
+// Discriminator.compute_grad_pen_combined (a2c/algo/gail.py:67-89), the VALUE of the penalty only: per row
+//   x = alpha e + (1 - alpha) p;  g = dD/dx(x) = W1^T[(1 - h1^2) . W2^T[(1 - h2^2) . w3]];  pen = (||g||_2 - 1)^2.
+// Not on the update path (the update kernels form the penalty and its double backward themselves): one workgroup per row,
+// plain FMAs from the canonical parameter layout.
+__global__ void __launch_bounds__(128) k_disc_grad_pen(SgDiscDesc d, const float* __restrict__ W, const float* __restrict__ e,
+                                                       const float* __restrict__ p, const float* __restrict__ alpha, int n,
+                                                       float* __restrict__ pen) {
+    extern __shared__ float sm[];
+    float* xm = sm;                 // [Fp]
+    float* h1 = xm + d.Fp;          // [Hp]
+    float* h2 = h1 + d.Hp;
+    float* d2 = h2 + d.Hp;
+    float* d1 = d2 + d.Hp;
+    float* red = d1 + d.Hp;         // [2]
+    const int r = blockIdx.x, t = threadIdx.x, F = d.F, Hd = d.Hd;
+    if (r >= n) return;
+    const float al = alpha[r];
+    for (int j = t; j < F; j += blockDim.x) xm[j] = al * e[(size_t)r * F + j] + (1.0f - al) * p[(size_t)r * F + j];
+    __syncthreads();
+    for (int i = t; i < Hd; i += blockDim.x) {
+        float a = W[d.b1 + i];
+        const float* w = W + d.w1 + (size_t)i * d.ldF;
+        for (int j = 0; j < F; ++j) a += w[j] * xm[j];
+        h1[i] = sg_tanh(a);
+    }
+    __syncthreads();
+    for (int i = t; i < Hd; i += blockDim.x) {
+        float a = W[d.b2 + i];
+        const float* w = W + d.w2 + (size_t)i * d.ldH;
+        for (int k = 0; k < Hd; ++k) a += w[k] * h1[k];
+        const float h = sg_tanh(a);
+        h2[i] = h;
+        d2[i] = W[d.w3 + i] * (1.0f - h * h);
+    }
+    __syncthreads();
+    for (int k = t; k < Hd; k += blockDim.x) {
+        float a = 0.f;
+        for (int i = 0; i < Hd; ++i) a += W[d.w2 + (size_t)i * d.ldH + k] * d2[i];
+        d1[k] = a * (1.0f - h1[k] * h1[k]);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int j = t; j < F; j += blockDim.x) {
+        float a = 0.f;
+        for (int i = 0; i < Hd; ++i) a += W[d.w1 + (size_t)i * d.ldF + j] * d1[i];
+        part += a * a;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((t & 63) == 0) red[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) {
+        const float nn = sqrtf(red[0] + red[1]);
+        pen[r] = (nn - 1.0f) * (nn - 1.0f);
+    }
 }
 
 // ------------------------------------------------------------------------ forward / rewards
@@ -295,8 +342,8 @@ extern "C" int sg_disc_create(sg_ctx* ctx, int input_dim, int hidden_dim, sg_dis
         SG_CHECK(hipStreamSynchronize(ctx->stream));
     }
     const size_t wT_f = (size_t)2 * d->desc.Hp * (d->desc.Fp + d->desc.Hp);   // images of W1, W2, W2^T, W1^T
-    SG_CHECK(sg_dev_malloc((void**)&d->d_wT, sizeof(float) * 2 * wT_f));   // two sets: k_disc_step4 double-buffers them by step parity
-    SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * 2 * wT_f, ctx->stream));
+    SG_CHECK(sg_dev_malloc((void**)&d->d_wT, sizeof(float) * wT_f));
+    SG_CHECK(hipMemsetAsync(d->d_wT, 0, sizeof(float) * wT_f, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_params, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_m, 0, sizeof(float) * tot, ctx->stream));
     SG_CHECK(hipMemsetAsync(d->d_v, 0, sizeof(float) * tot, ctx->stream));
@@ -598,7 +645,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
     const bool gw = disc_needs_gw(ctx, dd);
     const int n_chain_wg = thin ? 12 * G : 2 * G;
     // (two sets of partials: k_disc_step4 double-buffers them by step parity like the stacks; the two-launch forms use the first)
-    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)2 * 12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
+    const size_t ops_f = disc_ops_floats(dd, G), part_f = (size_t)12 * G * 4 * dd.Hp, grad_f = (size_t)dd.total + 8;
     if (d->n_slabs < G) {
         SG_CHECK(hipStreamSynchronize(ctx->stream));
         if (d->d_slabs) SG_CHECK(sg_dev_free(d->d_slabs));
@@ -679,11 +726,6 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
             if (k == 0) {   // the first step of the epoch has no predecessor to gather for it
                 pg.erows = d->d_erows; pg.prows = d->d_prows; pg.alpha = a.alpha; pg.ops = a.ops;
                 hipLaunchKernelGGL(k_disc_pregather, dim3(2 * G), dim3(512), 0, ctx->stream, pg);
-#if SG_STEP4_POISON
-                // k_disc_step4's hand-off: the words this step's chain workgroups will write start out poisoned (every later
-                // step's are poisoned by the launch before it)
-                if (fused) hipLaunchKernelGGL(k_disc_poison, dim3(96), dim3(512), 0, ctx->stream, a.ops, a.part, G, dd.Hp, dd.Fp, dd.ldF);
-#endif
             }
             pg.B = k + 1 < n_d ? step_cnt[k + 1] : 0;
             pg.erows = d->d_erows + (size_t)step_off[k + 1] * dd.F; pg.prows = d->d_prows + (size_t)step_off[k + 1] * dd.F;
@@ -694,7 +736,6 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                 Step4Args sa;
                 sa.next = pg; sa.loss_acc = d->d_loss_acc;
                 sa.dbg = (SG_STEP4_VERIFY || k == n_d - 2 || n_d < 2) ? d->d_dbg_step4 : nullptr;   // stamps: one representative step
-                sg_step4_poll_times(dd, &sa.poll_a, &sa.poll_b);
                 launch_disc_step4(ctx, dd, d, a.ops, a.B, G, wa.k1, sa);
                 continue;
             }
@@ -709,13 +750,6 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
                                    dd.total, a.st, 1e-8f, a.inv_B, a.lambda_, d->d_loss_acc, dd, d->d_wT, wa.k1);
             }
         }
-#if SG_STEP4_POISON
-        if (fused && (n_d & 1)) {   // the last step wrote image set 1: every epoch starts on set 0
-            const int n4 = (2 * dd.Hp * (dd.Fp + dd.Hp)) / 4;
-            hipLaunchKernelGGL(k_disc_img_copy, dim3(48), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(d->d_wT),
-                               reinterpret_cast<const float4*>(d->d_wT + 4 * (size_t)n4), n4);
-        }
-#endif
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, a.st, n_d);
         return 0;
     };
@@ -729,7 +763,7 @@ static int disc_update_core(sg_disc* d, const float* rows_local, int64_t TN_loc,
         const uint64_t key[12] = {(uint64_t)(uintptr_t)d->d_slabs, (uint64_t)(uintptr_t)d->d_eperm, (uint64_t)(uintptr_t)d->d_pperm,
                                   (uint64_t)(uintptr_t)d->d_alpha, (uint64_t)(uintptr_t)next_feat, (uint64_t)(uintptr_t)d->d_expert,
                                   (uint64_t)n_d, (uint64_t)B_loc, (uint64_t)batch_size,
-                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | (fused ? 8u : 0u) | (sg_comm_peer_on(ctx) ? 16u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f,
+                                  (uint64_t)thin | (sharded ? 2u : 0u) | (gw ? 4u : 0u) | (fused ? 8u : 0u) | (sg_comm_peer_on(ctx) ? 16u : 0u) | ((uint64_t)((replicated && world > 1) ? n_cols : 0) << 8), (uint64_t)ops_f | ((uint64_t)sg_comm_peer_generation(ctx) << 40),
                                   (uint64_t)(uintptr_t)d->d_erows ^ ((uint64_t)(uintptr_t)d->d_prows << 1)};
         if (!d->epoch_graph || memcmp(key, d->epoch_graph_key, sizeof key) != 0) {
             if (d->epoch_graph) { SG_CHECK(hipGraphExecDestroy(d->epoch_graph)); d->epoch_graph = nullptr; }
@@ -845,6 +879,32 @@ extern "C" int sg_disc_predict_reward(sg_disc* d, const float* x, int n, float g
     d->returns_none = false;
     SG_CHECK(hipMemcpyAsync(reward, d_rew, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipMemcpyAsync(returns, d->d_returns, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int sg_disc_grad_pen(sg_disc* d, const float* expert_rows, const float* policy_rows, const float* alpha, int n,
+                                uint64_t seed, float* pen) {
+    SG_REQUIRE(d && expert_rows && policy_rows && pen && n > 0, "sg_disc_grad_pen: bad argument");
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    const SgDiscDesc& dd = d->desc;
+    float* scratch = nullptr;
+    const size_t fx = (size_t)n * dd.F;
+    SG_TRY(sg_ctx_scratch(ctx, sizeof(float) * (2 * fx + 2 * (size_t)n), &scratch));
+    float *d_e = scratch, *d_p = d_e + fx, *d_al = d_p + fx, *d_pen = d_al + n;
+    SG_CHECK(hipMemcpyAsync(d_e, expert_rows, sizeof(float) * fx, hipMemcpyHostToDevice, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(d_p, policy_rows, sizeof(float) * fx, hipMemcpyHostToDevice, ctx->stream));
+    if (alpha) {
+        for (int i = 0; i < n; ++i) SG_REQUIRE(alpha[i] >= 0.f && alpha[i] <= 1.f, "sg_disc_grad_pen: alpha[%d] = %g is not in [0, 1]", i, (double)alpha[i]);
+        SG_CHECK(hipMemcpyAsync(d_al, alpha, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        hipLaunchKernelGGL(k_fill_alpha, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_al, (int64_t)n, seed, 0xA2000000ull);
+    }
+    const size_t lds = sizeof(float) * (size_t)(dd.Fp + 4 * dd.Hp + 2);
+    hipLaunchKernelGGL(k_disc_grad_pen, dim3((unsigned)n), dim3(128), lds, ctx->stream, dd, d->d_params, d_e, d_p, d_al, n, d_pen);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipMemcpyAsync(pen, d_pen, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     SG_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

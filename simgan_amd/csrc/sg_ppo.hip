@@ -22,7 +22,6 @@
 #include "sg_common.h"
 #include "sg_rng.hpp"
 #include "sg_ppo_kernels.hpp"
-#include "sg_ppo_small.hpp"
 
 __global__ void k_fill_perm(int64_t* perm, int64_t n, int half_bits, uint64_t key) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,17 +186,6 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     if (a->d_loss_acc) (void)sg_dev_free(a->d_loss_acc);
     if (a->d_dbg) (void)sg_dev_free(a->d_dbg);
     if (a->d_pair) (void)sg_dev_free(a->d_pair);
-#if SG_SMALL_STAMPS
-    if (a->d_small) {
-        unsigned long long h[32];
-        (void)hipMemcpy(h, a->d_small + 2 * SG_SMALL_MAX_TRUNKS * SG_SMALL_WORDS, sizeof h, hipMemcpyDeviceToHost);
-        for (int t = 0; t < 2; ++t)
-            fprintf(stderr, "[k_ppo_small stamps, trunk %d, last step; ns] body %lld, publish %lld, exchange %lld, norm %lld, adam %lld\n", t,
-                    10 * (long long)(h[t * 16 + 1] - h[t * 16 + 0]), 10 * (long long)(h[t * 16 + 2] - h[t * 16 + 1]), 10 * (long long)(h[t * 16 + 3] - h[t * 16 + 2]),
-                    10 * (long long)(h[t * 16 + 4] - h[t * 16 + 3]), 10 * (long long)(h[t * 16 + 5] - h[t * 16 + 4]));
-    }
-#endif
-    if (a->d_small) (void)sg_dev_free(a->d_small);
     if (a->steps_graph) (void)hipGraphExecDestroy(a->steps_graph);
     delete a;
     return 0;
@@ -257,7 +245,6 @@ extern "C" int sg_ppo_set_adam(sg_ppo* a, const float* m, const float* v, int64_
     // so the row stacks they live in are cleared before the next update
     a->scratch_key = 0;
     a->pair_primed = false;
-    a->small_primed = false;       // ... and so are k_ppo_small's words
     a->opt_t = step;
     return 0;
 }
@@ -369,12 +356,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // 16-row slabs would exceed 24 MB; otherwise 16-row groups (more workgroups in flight hide the phases' latencies)
     int MT = ((size_t)((mb + 15) / 16) * (size_t)(d.total + 8) * sizeof(float) > ((size_t)24 << 20) ||
               ((mb + 31) / 32) * d.n_trunks >= ctx->num_cu) ? 2 : 1;
-    // a Policy minibatch of at most 32 rows that can run as k_ppo_small (below): ONE row group, so that a trunk's whole gradient
-    // is formed in one workgroup
-    const char* senv = getenv("SG_PPO_SMALL");
-    const bool small_wanted = d.kind == SG_POLICY_MLP && d.n_trunks == 2 && mb <= 32 && !ctx->use_comm && !owned && !a->d_dbg && !a->self_wait_failed &&
-                              senv && strcmp(senv, "0") != 0;   // OPT-IN: measured slower than the three-launch step (profiles/r05_ppo_small_negative.txt)
-    if (small_wanted && mb > 16) MT = 2;
     if (const char* e = getenv("SG_PPO_ROWS")) {   // tuning knob
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) MT = v / 16;
@@ -439,7 +420,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
     pa.st = reinterpret_cast<SgOptState*>(a->d_state); pa.G = G; pa.k1 = 0;
     pa.pair = a->d_pair;
-    pa.gb_off = 0; pa.ls_off = 0; pa.stage_mask = -1;
     for (int t = 0; t < 3; ++t) {
         const bool on = t < d.n_trunks;
         pa.H1[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
@@ -467,21 +447,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
     a->pair_primed = pair;
     const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
-    // Policy whose minibatch is ONE row group (the reference's own CPU-runnable geometry: 32-row steps): one launch per EPOCH,
-    // a resident workgroup per trunk, weights / moments / gradient in LDS (k_ppo_small, sg_ppo_small.hpp).  Bit-identical to the
-    // three-launch step on the same row tiling, but 26 us per step against 18: SG_PPO_SMALL=1 selects it, the default does not.
-    const int small_gcap = (max_trunk_floats(d) + 8 + 3) & ~3;
-    const int small_npart = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
-    const size_t lds_small = lds_b + sizeof(float) * ((size_t)3 * small_gcap + ((small_npart + 3) & ~3) + 128 * SG_SMALL_MAX_TRUNKS + 16 + 2 * (size_t)M);
-    bool small = small_wanted && fused && !gw && G == 1 &&
-                 lds_small <= (size_t)ctx->lds_bytes && small_npart + 128 <= SG_SMALL_WORDS && d.trunk[0].size >= 64 && d.trunk[1].size >= 64;
-    for (int e = 0; small && e < E; ++e)
-        for (int k = 0; k < M; ++k) small = small && step_cnt[(size_t)e * M + k] == mb && step_off[(size_t)e * M + k] == k * mb;
-    if (small) {
-        if (!a->d_small) SG_CHECK(sg_dev_malloc((void**)&a->d_small, sizeof(unsigned long long) * (2 * SG_SMALL_MAX_TRUNKS * SG_SMALL_WORDS + 64)));
-        if (!a->small_primed) SG_CHECK(hipMemsetAsync(a->d_small, 0, sizeof(unsigned long long) * (2 * SG_SMALL_MAX_TRUNKS * SG_SMALL_WORDS + 64), ctx->stream));
-        a->small_primed = true;
-    }
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
@@ -495,21 +460,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
             ga.perm = a->d_perms + (size_t)e * TN;
             ga.TN = epoch_rows[e];
             if (ga.TN) hipLaunchKernelGGL(k_ppo_epoch_gather, dim3((unsigned)((ga.TN + 63) / 64)), dim3(256), 0, ctx->stream, ga);
-            if (small) {   // the epoch's M steps in one launch
-                pa.mb = mb;
-                pa.X = epX; pa.ACT = epACT; pa.SC = epSC;
-                pa.k1 = e * M + 1;
-                pa.wbuf_floats = wb_f;
-                SmallArgs sa;
-                sa.M = M; sa.rows_per_step = mb; sa.xbuf = a->d_small;
-                sa.params = a->policy->d_params; sa.m = a->d_m; sa.v = a->d_v; sa.loss_acc = a->d_loss_acc;
-                sa.eps = a->cfg.eps; sa.max_norm = a->cfg.max_grad_norm;
-                sa.extra_off = (int)(lds_b / sizeof(float)); sa.gcap = small_gcap;
-                const dim3 block(ppo_block_threads(MT));
-                if (MT == 2) SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_small<2, 0, 0>), dim3(2), block, lds_small, pa, sa);
-                else SG_LAUNCH(ctx, SG_PROF_PPO_BWD, (k_ppo_small<1, 0, 0>), dim3(2), block, lds_small, pa, sa);
-                continue;
-            }
             for (int k = 0; k < M; ++k) {
                 const size_t rb = (size_t)step_off[(size_t)e * M + k];
                 pa.mb = step_cnt[(size_t)e * M + k];
@@ -562,7 +512,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0) + (sg_comm_peer_on(ctx) ? 32 : 0) + (small ? 64 : 0)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0) + (sg_comm_peer_on(ctx) ? 32 : 0) + ((uint64_t)sg_comm_peer_generation(ctx) << 32)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {
@@ -580,15 +530,14 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     if (!out3) return 0;   // the caller reads the losses later (sg_results_publish): the update stays queued, no host wait
     double acc[3];
     SG_TRY(sg_ctx_fetch_f64(ctx, a->d_loss_acc, acc, 3));
-    if ((pair || small) && (acc[0] != acc[0] || acc[1] != acc[1] || acc[2] != acc[2])) {   // NaN: either the data, or a workgroup of k_ppo_pair / k_ppo_small gave up waiting
+    if (pair && (acc[0] != acc[0] || acc[1] != acc[1] || acc[2] != acc[2])) {   // NaN: either the data, or a workgroup of k_ppo_pair gave up waiting
         unsigned err = 0;
         SG_COPY_SYNC(ctx, &err, a->d_pair + SG_PAIR_ERR_WORD, sizeof err, hipMemcpyDeviceToHost);
         if (err) {
             SG_CHECK(hipMemsetAsync(a->d_pair + SG_PAIR_ERR_WORD, 0, sizeof err, ctx->stream));
             a->self_wait_failed = true;
-            SG_REQUIRE(false, "sg_ppo_update: a workgroup of %s waited %d s for its partner's words and gave "
-                       "up (the policy's state is undefined; SG_PPO_PAIR=0 / SG_PPO_SMALL=0 run the multi-launch step)", small ? "k_ppo_small" : "k_ppo_pair",
-                       (int)(SG_PAIR_TIMEOUT_TICKS / 100000000ll));
+            SG_REQUIRE(false, "sg_ppo_update: a workgroup of k_ppo_pair waited %d s for its partner's words and gave "
+                       "up (the policy's state is undefined; SG_PPO_PAIR=0 runs the multi-launch step)", (int)(SG_PAIR_TIMEOUT_TICKS / 100000000ll));
         }
     }
     const double nu = (double)E * M;

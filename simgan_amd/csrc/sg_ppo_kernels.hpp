@@ -46,10 +46,6 @@ struct PpoArgs {
     SgOptState* st;       // optimizer scalars (read by k_ppo_adam; prepared one step ahead by the previous k_ppo_adam)
     int k1, G;            // 1-based step index within the update; row groups
     unsigned* pair;       // k_ppo_pair: the error word an actor workgroup raises when its partner never shows up
-    int gb_off, ls_off;   // k_ppo_small (RESIDENT body): float offsets in LDS of the trunk's gradient buffer and of the loss sums
-    int stage_mask;       // -1: the trunk's block is staged into LDS; 0 (k_ppo_small): it is resident there, nothing is loaded.  A run-time
-                          // value on purpose: with the staging compiled out this compiler's back end stops on an illegal
-                          // "v_cmp_ne_u32 0, src_shared_base" (ROCm 7.2 clang, gfx950)
 };
 
 // k_ppo_pair (SplitPolicy, one launch per step): the two actor workgroups of a row group exchange their head outputs
@@ -188,9 +184,7 @@ __global__ __launch_bounds__(512) void k_ppo_fwd(PpoArgs a) {
 // stacks and the loss code below is unchanged: results are bit-identical to the two-launch step.  Both workgroups wait for each
 // other, so they must be resident together: they are neighbours in dispatch order (trunk index fastest) and the launch is only
 // used when all its workgroups fit the chip at once; the spin is bounded by the wall clock all the same.
-// RESIDENT (k_ppo_small): the gradient and the loss sums go to LDS buffers; the trunk's block is already in LDS (and is the
-// only up-to-date copy): a.stage_mask = 0 keeps it from being staged.
-template <int MT, int KO, int KH, bool FUSED, bool GW = false, bool PAIR = false, bool RESIDENT = false>
+template <int MT, int KO, int KH, bool FUSED, bool GW = false, bool PAIR = false>
 __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (No spare workgroup for Adam's bias corrections any more: with G x trunks = 256 row-group blocks, two extra blocks
@@ -230,7 +224,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     if (PAIR && !critic) pair_tag = (unsigned)(a.st->t0 + a.k1);
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
-    if (!GW) sg_stage_issue<12>(wv, a.params + tr.off + w_first, (wfl / 4) & a.stage_mask);
+    if (!GW) sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
     constexpr int UX = MT <= 2 ? 4 : 8;          // float4 per thread for an [R][ld <= 116] tile at 256 threads
     constexpr int UO = MT <= 2 ? 2 : 4;          // ... for an [R][ldP <= 64] tile
     const int ta = critic ? t : 0;
@@ -276,7 +270,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
     SG_PPO_STAMP(0);
-    if (!GW) sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, (wfl / 4) & a.stage_mask);
+    if (!GW) sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
     __syncthreads();
     SG_PPO_STAMP(1);
     if (FUSED) {   // forward on this row group (a2c/model.py:255-264, a2c/distributions.py:109-118), activations stay in LDS
@@ -486,14 +480,14 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         float s0 = tid < R ? ROWL[tid] : 0.f, s1 = (tid < R && !critic) ? ROWL[R + tid] : 0.f;
         s0 = sg_wave_sum(s0); s1 = sg_wave_sum(s1);
         if (tid == 0) {
-            float* ls = RESIDENT ? smem + a.ls_off : slab + d.total;
+            float* ls = slab + d.total;
             if (critic) ls[0] = s0;
             else { ls[1] = s0; ls[2] = s1; }
         }
     }
-    float* g = RESIDENT ? smem + a.gb_off : slab + tr.off;   // (RESIDENT: the gradient stays in LDS; a compile-time choice, so that no pointer is of two address spaces)
+    float* g = slab + tr.off;
     // head weight / bias gradients (needs h2 before it is overwritten)
-    sg_grad_tn<MT, (MT >= 2 ? 8 : 0), !RESIDENT>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
+    sg_grad_tn<MT, (MT >= 2 ? 8 : 0), true>(dout, ldP, H2, ldH, tr.Pp, Hp, g + tr.wh, ldH, false);
     sg_colsum(dout, ldP, R, tr.Pp, g + tr.bh, false);
     if (tr.EX) sg_colsum(O1, ldP, R, SG_PAD16(tr.EX), g + tr.ex, false);
     SG_LDS_SYNC();
@@ -504,7 +498,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         sg_layer_nn_u<MT>(dout, ldP, W + tr.wh, ldH, tr.Pp, Hp, dz_u(H2));
         SG_LDS_SYNC();
         SG_PPO_STAMP(12);
-        sg_grad_tn<MT, (MT >= 2 ? 8 : 0), !RESIDENT>(H2, ldH, H1, ldH, Hp, Hp, g + tr.w2, ldH, false);
+        sg_grad_tn<MT, (MT >= 2 ? 8 : 0), true>(H2, ldH, H1, ldH, Hp, Hp, g + tr.w2, ldH, false);
         SG_PPO_STAMP(5);
         sg_colsum(H2, ldH, R, Hp, g + tr.b2, false);
         SG_LDS_SYNC();
@@ -512,7 +506,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         sg_layer_nn_u<MT>(H2, ldH, W + tr.w2, ldH, Hp, Hp, dz_u(H1));
         SG_LDS_SYNC();
         SG_PPO_STAMP(14);
-        sg_grad_tn<MT, (MT >= 2 ? 8 : 0), !RESIDENT>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
+        sg_grad_tn<MT, (MT >= 2 ? 8 : 0), true>(H1, ldH, X, ldO, Hp, Op, g + tr.w1, ldO, false);
         sg_colsum(H1, ldH, R, Hp, g + tr.b1, false);
         SG_LDS_SYNC();
     }

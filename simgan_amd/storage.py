@@ -10,6 +10,8 @@ reference's shapes.  The HBM copy inside libsimgan_hip.so is refreshed per opera
     attribute that is re-bound is a different tensor.  So `obs_feat` crosses PCIe once per rollout, not once per
     discriminator epoch.  Writes torch cannot see (through a `.numpy()` view of the attribute) need
     `mark_host_written()`; without torch (plain numpy mirrors) and with SG_ROLLOUT_ALWAYS_UPLOAD=1 every call uploads;
+    SG_ROLLOUT_VERIFY=1 (debugging a port) checksums every field the tracker takes for unchanged and raises when it was
+    written behind torch's back;
   * `device_resident = True` (driver / bench fast path): uploads are skipped, the device copy is
     the source of truth and `sync_from_device()` refreshes the host view on demand.
 """
@@ -21,6 +23,8 @@ import numpy as np
 
 from . import _lib
 from .utils import to_host_tensor, torch
+
+_VERIFY = os.environ.get("SG_ROLLOUT_VERIFY") == "1"
 
 _FIELD_ATTR = {
     _lib.F_OBS: "obs", _lib.F_OBS_FEAT: "obs_feat", _lib.F_ACTIONS: "actions",
@@ -62,6 +66,7 @@ class RolloutStorage(object):
         self._device_resident = False
         self._host_written = False   # insert() wrote host slots since the last after_update()
         self._synced = {}            # field -> (weakref of the host tensor, its _version) when the device copy last matched it
+        self._crcs = {}              # SG_ROLLOUT_VERIFY=1: field -> crc32 of the host content at that moment
         self.bytes_uploaded = 0      # host -> device traffic of this rollout so far (bench.py's `dropin` leg reads it)
 
         h = _lib.H()
@@ -113,6 +118,10 @@ class RolloutStorage(object):
         for f in (fields if fields is not None else list(self._synced)):
             self._synced.pop(f, None)
 
+    def _crc(self, field):
+        import zlib
+        return zlib.crc32(self._host_np(field))
+
     def sync_to_device(self, fields=None):
         for f in (fields if fields is not None else _FIELD_ATTR):
             a = self._host_np(f)
@@ -120,6 +129,8 @@ class RolloutStorage(object):
                 _lib.check(self.lib.sg_rollout_upload(self.h, f, _lib.fptr(a), a.size))
                 self.bytes_uploaded += a.nbytes
             self._synced[f] = self._stamp(f)
+            if _VERIFY:
+                self._crcs[f] = self._crc(f)
 
     def sync_from_device(self, fields=None):
         for f in (fields if fields is not None else _FIELD_ATTR):
@@ -127,6 +138,8 @@ class RolloutStorage(object):
             if a.size:
                 _lib.check(self.lib.sg_rollout_download(self.h, f, _lib.fptr(a), a.size))
             self._synced[f] = self._stamp(f)   # (written through the numpy view: the version counter did not move)
+            if _VERIFY:
+                self._crcs[f] = self._crc(f)
 
     def _push(self, fields):
         if self.device_resident:
@@ -134,6 +147,15 @@ class RolloutStorage(object):
         if os.environ.get("SG_ROLLOUT_ALWAYS_UPLOAD") == "1":
             return self.sync_to_device(fields)
         stale = [f for f in fields if not self._matches(f)]
+        if _VERIFY:
+            # SG_ROLLOUT_VERIFY=1: a field the tracker takes for unchanged is checksummed against what was uploaded -- a write that
+            # did not go through torch (rollouts.x.numpy()[...] = ..., a .data view, an array shared through torch.from_numpy, C or
+            # environment code filling the buffer) is then an error here instead of a silently stale device copy
+            for f in fields:
+                if f not in stale and f in self._crcs and self._crc(f) != self._crcs[f]:
+                    raise RuntimeError(f"rollouts.{_FIELD_ATTR[f]} was written behind torch's version counter since its last upload "
+                                       "(a numpy view / .data / shared buffer): call rollouts.mark_host_written() after such writes, "
+                                       "or set SG_ROLLOUT_ALWAYS_UPLOAD=1")
         if stale:
             self.sync_to_device(stale)
 

@@ -89,3 +89,15 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(src), f"{os.path.join(dirpath, f)} uses the oracle"
+
+
+def test_no_kernel_of_the_product_library_spills_to_scratch():
+    """Every kernel of libsimgan_hip.so keeps its state in registers and LDS: no VGPR spills, no private-segment (scratch) bytes
+    (round 5 shipped one that round-tripped through scratch; tools/check_codeobj.py reads the code objects' metadata notes)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_codeobj
+    ks = check_codeobj.kernels(os.path.join(ROOT, "simgan_amd", "libsimgan_hip.so"))
+    assert len(ks) > 50, len(ks)
+    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k["vgpr_spill"] or k["scratch"]]
+    assert not bad, bad

@@ -178,3 +178,24 @@ def test_literal_main_sequence_equals_the_resident_learner(sg):
     p_a, p_b = pol.get_flat_params(), pol_r.get_flat_params()
     move = np.linalg.norm(p_a.astype(np.float64) - build()[0].get_flat_params())
     assert np.linalg.norm(p_a.astype(np.float64) - p_b) <= 2e-2 * move, "policies of the two modes drifted apart"
+
+
+def test_verify_mode_catches_a_write_behind_torchs_back(sg, orc, monkeypatch):
+    """SG_ROLLOUT_VERIFY=1 (simgan_amd/storage.py): a write through a numpy view of a host tensor does not move torch's version
+    counter, so the dirty tracker would train on the stale device copy -- in verify mode the next device call raises instead;
+    mark_host_written() is the remedy, and writes torch can see never trip it."""
+    from simgan_amd import storage
+    monkeypatch.setattr(storage, "_VERIFY", True)
+    ro, rng = _filled(sg)
+    T, N = ro.num_steps, ro.num_processes
+    nv = rng.standard_normal(N).astype(np.float32)
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    ro.rewards[2] = ro.rewards[2] * 0.5                      # visible to torch: fine
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert_close(ro.returns.numpy()[:T, :, 0], _oracle_returns(orc, ro, nv)[:T], rtol=1e-5, what="returns after a visible edit")
+    ro.rewards.numpy()[5] += 2.0                            # behind torch's back
+    with pytest.raises(RuntimeError, match="mark_host_written"):
+        ro.compute_returns(nv, True, 0.99, 0.95, True)
+    ro.mark_host_written()
+    ro.compute_returns(nv, True, 0.99, 0.95, True)
+    assert_close(ro.returns.numpy()[:T, :, 0], _oracle_returns(orc, ro, nv)[:T], rtol=1e-5, what="returns after mark_host_written")

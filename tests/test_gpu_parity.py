@@ -726,6 +726,31 @@ def test_predict_prob_single_step(sg, orc):
     assert isinstance(s0, float) and s0 == pytest.approx(float(s_ref[0]), rel=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["small", "northstar"])
+def test_grad_pen_value_golden(sg, orc, tag):
+    """Discriminator.compute_grad_pen_combined / compute_grad_pen (a2c/algo/gail.py:53-89): the penalty's value on the reference's
+    rows with its torch.rand draw injected, against the reference's scalar; with the library's own draw, against the oracle on
+    the alphas the library reports nothing about -- so only its range is checked there."""
+    g = load("grad_pen")
+    m = g["meta"][tag]
+    F, n, sp = m["F"], m["n"], m["split"]
+    D = sg.algo.gail.Discriminator(F, m["Hd"], None, seed=9)
+    D.set_flat_params(g[f"{tag}_params"])
+    e, p = g[f"{tag}_expert"], g[f"{tag}_policy"]
+    v = D.compute_grad_pen_combined(e, p, 10.0, alpha=g[f"{tag}_alpha"])
+    assert np.asarray(v).shape == () and np.asarray(v).dtype == np.float32
+    assert_close(v, g[f"{tag}_value"], what="compute_grad_pen_combined")
+    assert_close(v, orc.disc_grad_pen(F, m["Hd"], g[f"{tag}_params"], e, p, g[f"{tag}_alpha"], 10.0), what="... vs oracle")
+    v2 = D.compute_grad_pen(e[:, :sp], e[:, sp:], p[:, :sp], p[:, sp:], lambda_=4.0, alpha=g[f"{tag}_alpha2"])
+    assert_close(v2, g[f"{tag}_value2"], what="compute_grad_pen")
+    # the call changes no state, and the library's own draw gives a value between the per-row extremes over alpha in [0, 1]
+    assert np.array_equal(D.get_flat_params(), g[f"{tag}_params"])
+    v3 = float(D.compute_grad_pen_combined(e, p, 10.0))
+    assert np.isfinite(v3) and v3 >= 0.0 and v3 != float(v)
+    with pytest.raises(Exception):
+        D.compute_grad_pen_combined(e, p, 10.0, alpha=np.full(n, 1.5, np.float32))
+
+
 def test_predict_reward_state_action_golden(sg):
     """Discriminator.predict_reward (a2c/algo/gail.py:195-199) against the reference's own output, two calls with
     Discriminator.returns carried between them."""

@@ -171,6 +171,16 @@ def test_predict_reward_state_action():
         assert_close(ret, g[f"returns{c}"], what=f"returns, call {c}")
 
 
+@pytest.mark.parametrize("tag", ["small", "northstar"])
+def test_grad_pen_value(tag):
+    """Discriminator.compute_grad_pen_combined / compute_grad_pen (a2c/algo/gail.py:53-89) on the reference's rows and draws."""
+    g = load("grad_pen")
+    m = g["meta"][tag]
+    for suffix, lam in (("", 10.0), ("2", 4.0)):
+        v = orc.disc_grad_pen(m["F"], m["Hd"], g[f"{tag}_params"], g[f"{tag}_expert"], g[f"{tag}_policy"], g[f"{tag}_alpha{suffix}"], lam)
+        assert_close(v, g[f"{tag}_value{suffix}"], what=f"grad_pen {tag}{suffix}")
+
+
 @pytest.mark.parametrize("name", ["iter_mlp", "iter_split"])
 def test_full_iteration(name):
     """a2c/main_gail_dyn_ppo.py:239-304 restated with oracle calls, 2 outer iterations."""

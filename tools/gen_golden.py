@@ -624,6 +624,32 @@ def gen_predict_reward():
     save("predict_reward", meta=meta(S=S, A=Ad, Hd=Hd, n=n, gamma=0.97), **out)
 
 
+def gen_grad_pen():
+    """Discriminator.compute_grad_pen_combined / compute_grad_pen (a2c/algo/gail.py:53-89): the penalty's value for given
+    expert / policy rows, with the torch.rand(n, 1) draw recorded."""
+    out, m = {}, {}
+    for tag, F, Hd, n, split, seed in (("small", 9, 16, 11, 6, 730), ("northstar", 86, 100, 128, 74, 740)):
+        torch.manual_seed(seed)
+        D = ns.Discriminator(F, Hd, "cpu")
+        with torch.no_grad():
+            for q in D.trunk.parameters():      # default init keeps ||dD/dx|| small: spread the norms around 1
+                q.mul_(2.5)
+        g = torch.Generator().manual_seed(seed + 1)
+        e, p = torch.randn(n, F, generator=g) * 0.8 + 0.1, torch.randn(n, F, generator=g)
+        _REC.clear()
+        torch.manual_seed(seed + 2)
+        v = D.compute_grad_pen_combined(e, p, 10.0)
+        alpha = [r for k, r in _REC if k == "rand"][0].reshape(-1).astype(np.float32)
+        _REC.clear()
+        torch.manual_seed(seed + 3)
+        v2 = D.compute_grad_pen(e[:, :split], e[:, split:], p[:, :split], p[:, split:], lambda_=4.0)
+        alpha2 = [r for k, r in _REC if k == "rand"][0].reshape(-1).astype(np.float32)
+        out.update({f"{tag}_params": flat_params(D.trunk), f"{tag}_expert": e.numpy(), f"{tag}_policy": p.numpy(), f"{tag}_alpha": alpha,
+                    f"{tag}_value": np.float32(v.item()), f"{tag}_alpha2": alpha2, f"{tag}_value2": np.float32(v2.item())})
+        m[tag] = dict(F=F, Hd=Hd, n=n, split=split)
+    save("grad_pen", meta=meta(**m), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: python tools/gen_golden.py refine vecnormalize checkpoints
         for what in sys.argv[1:]:
@@ -642,6 +668,8 @@ if __name__ == "__main__":
             elif what == "closures":
                 gen_ffgen()
                 gen_predict_reward()
+            elif what == "grad_pen":
+                gen_grad_pen()
             else:
                 raise SystemExit(f"unknown fixture group {what}")
         sys.exit(0)
@@ -674,3 +702,4 @@ if __name__ == "__main__":
     gen_vecnormalize()
     gen_ffgen()
     gen_predict_reward()
+    gen_grad_pen()
