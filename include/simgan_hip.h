@@ -237,6 +237,12 @@ SG_API int sg_disc_predict_reward(sg_disc *d, const float *x, int n, float gamma
                            float offset, float *reward, float *returns);
 /* Discriminator.predict_prob_single_step(s, a, s_n) a2c/algo/gail.py:212-217: prob[n] = sigmoid(D(x)) on the
  * caller-concatenated rows x[n,F]. */
+/* The T consecutive predict_reward_combined calls of the reference main's relabel loop (a2c/main_gail_dyn_ppo.py:275-280:
+ * call t passes obs_feat[t + 1], masks[t]) in ONE pass over the rollout's device copy of obs_feat and masks: reward[t*N + n] and
+ * returns[t*N + n] are bit for bit what the t-th sg_disc_predict_reward call returns, Discriminator.returns (a2c/algo/gail.py:206-209)
+ * is left where the T-th call leaves it.  The host mirror (simgan_amd/algo/gail.py) uses it to serve the unchanged main's 128 calls
+ * from one launch; the rollout's fields must be current on the device (sg_rollout_upload). */
+SG_API int sg_disc_predict_reward_steps(sg_disc *d, sg_rollout *r, float gamma, float offset, float *reward, float *returns);
 SG_API int sg_disc_predict_prob(sg_disc *d, const float *x, int n, float *prob);
 /* Discriminator.compute_grad_pen_combined(expert_combined, policy_combined, lambda_) a2c/algo/gail.py:67-89 (and
  * compute_grad_pen :53-65 on caller-concatenated rows), the VALUE only: pen[i] = (||dD/dx(alpha_i e_i + (1 - alpha_i) p_i)||_2 - 1)^2

@@ -11,6 +11,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# oracle/oracle64.py executes this file a second time with REAL_BITS = 64: the float64 ARBITER (sg_oracle_f64.c), same functions
+# on float64 arrays.  32 (the default, `from oracle import oracle`) is the parity oracle.
+REAL_BITS = globals().get("REAL_BITS", 32)
+_R = np.float32 if REAL_BITS == 32 else np.float64
+_CR = C.c_float if REAL_BITS == 32 else C.c_double
+_SO, _SRC = ("libsg_oracle.so", "sg_oracle.c") if REAL_BITS == 32 else ("libsg_oracle64.so", "sg_oracle_f64.c")
 
 KIND_MLP, KIND_SPLIT = 0, 1
 
@@ -21,18 +27,18 @@ class PolicyDims(C.Structure):
 
 
 class PPOCfg(C.Structure):
-    _fields_ = [("clip_param", C.c_float), ("ppo_epoch", C.c_int), ("num_mini_batch", C.c_int),
-                ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float), ("lr", C.c_float),
-                ("eps", C.c_float), ("max_grad_norm", C.c_float),
+    _fields_ = [("clip_param", _CR), ("ppo_epoch", C.c_int), ("num_mini_batch", C.c_int),
+                ("value_loss_coef", _CR), ("entropy_coef", _CR), ("lr", _CR),
+                ("eps", _CR), ("max_grad_norm", _CR),
                 ("use_clipped_value_loss", C.c_int)]
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libsg_oracle.so")
-    src = os.path.join(_HERE, "sg_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libsg_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+    so = os.path.join(_HERE, _SO)
+    srcs = [os.path.join(_HERE, "sg_oracle.c"), os.path.join(_HERE, _SRC)]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", _SO],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return so
 
 
@@ -42,7 +48,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_policy_num_params.restype = C.c_int64
         _LIB.orc_disc_num_params.restype = C.c_int64
-        _LIB.orc_clip_grad_norm.restype = C.c_float
+        _LIB.orc_clip_grad_norm.restype = _CR
         _LIB.orc_alive_bonus.restype = C.c_double
         _LIB.orc_disc_update.restype = C.c_int
     return _LIB
@@ -84,13 +90,23 @@ def fast_lib(native=False):
 
 
 def _f(a):
+    a = np.ascontiguousarray(a, dtype=_R)
+    return a, a.ctypes.data_as(C.POINTER(_CR))
+
+
+def _f32(a):   # the vectorised CPU baseline (sg_cpu_fast.c) is float32 whatever REAL_BITS says
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def _fp(a):  # in-place float32 array -> pointer (must already be contiguous float32)
+def _fp32(a):
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _fp(a):  # in-place float32 array -> pointer (must already be contiguous float32)
+    assert a.dtype == _R and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(_CR))
 
 
 def _i64(a):
@@ -115,9 +131,9 @@ def policy_forward(d, params, obs):
     obs, po = _f(obs)
     n = obs.shape[0]
     params, pp = _f(params)
-    value = np.empty((n, 1), np.float32)
-    mean = np.empty((n, d.A), np.float32)
-    logstd = np.empty((n, d.A), np.float32)
+    value = np.empty((n, 1), _R)
+    mean = np.empty((n, d.A), _R)
+    logstd = np.empty((n, d.A), _R)
     lib().orc_policy_forward(C.byref(d), pp, po, n, _fp(value), _fp(mean), _fp(logstd))
     return value, mean, logstd
 
@@ -126,9 +142,9 @@ def policy_act(d, params, obs, noise=None):
     obs, po = _f(obs)
     n = obs.shape[0]
     params, pp = _f(params)
-    value = np.empty((n, 1), np.float32)
-    action = np.empty((n, d.A), np.float32)
-    logp = np.empty((n, 1), np.float32)
+    value = np.empty((n, 1), _R)
+    action = np.empty((n, d.A), _R)
+    logp = np.empty((n, 1), _R)
     if noise is None:
         pn = None
     else:
@@ -142,9 +158,9 @@ def policy_evaluate(d, params, obs, action):
     action, pa = _f(action)
     n = obs.shape[0]
     params, pp = _f(params)
-    value = np.empty((n, 1), np.float32)
-    logp = np.empty((n, 1), np.float32)
-    ent = C.c_float(0)
+    value = np.empty((n, 1), _R)
+    logp = np.empty((n, 1), _R)
+    ent = _CR(0)
     lib().orc_policy_evaluate(C.byref(d), pp, po, pa, n, _fp(value), _fp(logp), C.byref(ent))
     return value, logp, float(ent.value)
 
@@ -154,13 +170,13 @@ def compute_returns(rewards, value_preds, masks, bad_masks, next_value, use_gae,
     """rewards [T,N]; value_preds/masks/bad_masks [T+1,N]; returns (returns[T+1,N], value_preds')."""
     rewards, pr = _f(rewards)
     T, N = rewards.shape[:2]
-    vp = np.array(value_preds, dtype=np.float32, copy=True).reshape(T + 1, N)
-    ret = np.zeros((T + 1, N), np.float32)
+    vp = np.array(value_preds, dtype=_R, copy=True).reshape(T + 1, N)
+    ret = np.zeros((T + 1, N), _R)
     masks, pm = _f(masks)
     bad_masks, pb = _f(bad_masks)
     next_value, pn = _f(next_value)
     lib().orc_compute_returns(T, N, pr, _fp(vp), _fp(ret), pm, pb, pn, int(use_gae),
-                              C.c_float(gamma), C.c_float(lam), int(proper_time_limits))
+                              _CR(gamma), _CR(lam), int(proper_time_limits))
     return ret, vp
 
 
@@ -168,7 +184,7 @@ def advantages(returns, value_preds):
     returns, pr = _f(returns)
     value_preds, pv = _f(value_preds)
     n = returns.size
-    adv = np.empty(n, np.float32)
+    adv = np.empty(n, _R)
     lib().orc_advantages(pr, pv, C.c_int64(n), _fp(adv))
     return adv
 
@@ -181,8 +197,8 @@ def ppo_cfg(clip_param=0.2, ppo_epoch=10, num_mini_batch=16, value_loss_coef=0.5
 
 class AdamState:
     def __init__(self, n):
-        self.m = np.zeros(n, np.float32)
-        self.v = np.zeros(n, np.float32)
+        self.m = np.zeros(n, _R)
+        self.v = np.zeros(n, _R)
         self.t = C.c_int64(0)
 
 
@@ -196,48 +212,48 @@ def ppo_grad_rows(d, params, cfg, obs, actions, value_preds, returns, old_logp, 
     old_logp, pl = _f(old_logp)
     adv, pad = _f(adv)
     rows, prow = _i64(rows)
-    G = np.zeros(params.size, np.float32)
+    G = np.zeros(params.size, _R)
     sums = (C.c_double * 3)(0, 0, 0)
     lib().orc_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
-                            int(rows.size), C.c_float(inv_B), _fp(G), sums)
+                            int(rows.size), _CR(inv_B), _fp(G), sums)
     return G, np.array(list(sums))
 
 
 def ppo_grad_rows_fast(d, params, cfg, obs, actions, value_preds, returns, old_logp, adv, rows, inv_B, native=False, n_threads=1):
     """oracle/sg_cpu_fast.c:fast_ppo_grad_rows -- same contract as ppo_grad_rows, batched GEMMs (n_threads > 1: rows split
     over an OpenMP team)."""
-    params, pp = _f(params)
-    obs, po = _f(obs)
-    actions, pa = _f(actions)
-    value_preds, pv = _f(value_preds)
-    returns, pr = _f(returns)
-    old_logp, pl = _f(old_logp)
-    adv, pad = _f(adv)
+    params, pp = _f32(params)
+    obs, po = _f32(obs)
+    actions, pa = _f32(actions)
+    value_preds, pv = _f32(value_preds)
+    returns, pr = _f32(returns)
+    old_logp, pl = _f32(old_logp)
+    adv, pad = _f32(adv)
     rows, prow = _i64(rows)
     G = np.zeros(params.size, np.float32)
     sums = (C.c_double * 3)(0, 0, 0)
     if n_threads > 1:
         fast_lib(native)[0].fast_ppo_grad_rows_mt(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow, int(rows.size),
-                                                  C.c_float(inv_B), _fp(G), sums, int(n_threads), C.c_int64(params.size))
+                                                  C.c_float(inv_B), _fp32(G), sums, int(n_threads), C.c_int64(params.size))
     else:
         fast_lib(native)[0].fast_ppo_grad_rows(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
-                                               int(rows.size), C.c_float(inv_B), _fp(G), sums)
+                                               int(rows.size), C.c_float(inv_B), _fp32(G), sums)
     return G, np.array(list(sums))
 
 
 def disc_grad_rows_fast(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda_=10.0, native=False, n_threads=1):
     """oracle/sg_cpu_fast.c:fast_disc_grad_rows -- same contract as disc_grad_rows, batched GEMMs."""
-    params, pp = _f(params)
-    expert_rows, pe = _f(expert_rows)
-    policy_rows, ppol = _f(policy_rows)
-    alpha, pal = _f(alpha)
+    params, pp = _f32(params)
+    expert_rows, pe = _f32(expert_rows)
+    policy_rows, ppol = _f32(policy_rows)
+    alpha, pal = _f32(alpha)
     nb = expert_rows.shape[0]
     G = np.zeros(params.size, np.float32)
     sums = (C.c_double * 3)(0, 0, 0)
     if n_threads > 1:
-        fast_lib(native)[0].fast_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums, int(n_threads))
+        fast_lib(native)[0].fast_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp32(G), sums, int(n_threads))
     else:
-        fast_lib(native)[0].fast_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp(G), sums)
+        fast_lib(native)[0].fast_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_), _fp32(G), sums)
     return G, np.array(list(sums))
 
 
@@ -251,10 +267,10 @@ def ppo_grad_rows_mt(d, params, cfg, obs, actions, value_preds, returns, old_log
     old_logp, pl = _f(old_logp)
     adv, pad = _f(adv)
     rows, prow = _i64(rows)
-    G = np.zeros(params.size, np.float32)
+    G = np.zeros(params.size, _R)
     sums = (C.c_double * 3)(0, 0, 0)
     lib().orc_ppo_grad_rows_mt(C.byref(d), pp, C.byref(cfg), po, pa, pv, pr, pl, pad, prow,
-                               int(rows.size), C.c_float(inv_B), _fp(G), sums, int(n_threads))
+                               int(rows.size), _CR(inv_B), _fp(G), sums, int(n_threads))
     return G, np.array(list(sums))
 
 
@@ -264,9 +280,9 @@ def disc_grad_rows_mt(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, n_t
     policy_rows, ppol = _f(policy_rows)
     alpha, pal = _f(alpha)
     nb = expert_rows.shape[0]
-    G = np.zeros(params.size, np.float32)
+    G = np.zeros(params.size, _R)
     sums = (C.c_double * 3)(0, 0, 0)
-    lib().orc_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_),
+    lib().orc_disc_grad_rows_mt(F, Hd, pp, pe, ppol, pal, nb, _CR(inv_B), _CR(lambda_),
                                 _fp(G), sums, int(n_threads))
     return G, np.array(list(sums))
 
@@ -287,7 +303,7 @@ def ppo_update(d, params, adam, cfg, obs, actions, value_preds, returns, old_log
     returns, pr = _f(returns)
     old_logp, pl = _f(old_logp)
     perms, pperm = _i64(perms)
-    out = (C.c_float * 3)()
+    out = (_CR * 3)()
     lib().orc_ppo_update(C.byref(d), _fp(params), _fp(adam.m), _fp(adam.v), C.byref(adam.t),
                          C.byref(cfg), T, N, po, pa, pv, pr, pl, pperm, out)
     return tuple(float(x) for x in out)
@@ -299,9 +315,9 @@ def disc_grad_rows(F, Hd, params, expert_rows, policy_rows, alpha, inv_B, lambda
     policy_rows, ppol = _f(policy_rows)
     alpha, pal = _f(alpha)
     nb = expert_rows.shape[0]
-    G = np.zeros(params.size, np.float32)
+    G = np.zeros(params.size, _R)
     sums = (C.c_double * 3)(0, 0, 0)
-    lib().orc_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, C.c_float(inv_B), C.c_float(lambda_),
+    lib().orc_disc_grad_rows(F, Hd, pp, pe, ppol, pal, nb, _CR(inv_B), _CR(lambda_),
                              _fp(G), sums)
     return G, np.array(list(sums))
 
@@ -311,12 +327,12 @@ def disc_grad_pen(F, Hd, params, expert_rows, policy_rows, alpha, lambda_=10.0):
     (orc_disc_grad_rows' third sum; its gradient output is discarded)."""
     n = np.asarray(expert_rows).shape[0]
     _, sums = disc_grad_rows(F, Hd, params, expert_rows, policy_rows, alpha, 1.0 / n, lambda_)
-    return np.float32(lambda_) * np.float32(sums[2] / n)
+    return _R(lambda_) * _R(sums[2] / n)
 
 
 def adam_step(params, G, adam, lr, eps):
     lib().orc_adam_step(_fp(params), _fp(G), _fp(adam.m), _fp(adam.v), C.byref(adam.t),
-                        C.c_int64(params.size), C.c_float(lr), C.c_float(eps))
+                        C.c_int64(params.size), _CR(lr), _CR(eps))
 
 
 def disc_update(F, Hd, params, adam, expert, obs_feat, B, expert_perm, policy_perm, alpha,
@@ -328,9 +344,9 @@ def disc_update(F, Hd, params, adam, expert, obs_feat, B, expert_perm, policy_pe
     expert_perm, pep = _i64(expert_perm)
     policy_perm, ppp = _i64(policy_perm)
     alpha, pal = _f(alpha)
-    out = (C.c_float * 3)()
+    out = (_CR * 3)()
     n_d = lib().orc_disc_update(F, Hd, _fp(params), _fp(adam.m), _fp(adam.v), C.byref(adam.t),
-                                C.c_float(lr), C.c_float(eps), pe, C.c_int64(expert.shape[0]), pf,
+                                _CR(lr), _CR(eps), pe, C.c_int64(expert.shape[0]), pf,
                                 T, N, B, pep, ppp, pal, out)
     return tuple(float(x) for x in out), n_d
 
@@ -342,9 +358,9 @@ def disc_predict_reward(F, Hd, params, x, gamma, masks, offset, returns=None):
     n = x.shape[0]
     masks, pm = _f(masks)
     first = returns is None
-    ret = np.zeros(n, np.float32) if first else np.array(returns, np.float32).reshape(n).copy()
-    reward = np.empty(n, np.float32)
-    lib().orc_disc_predict_reward(F, Hd, pp, px, n, C.c_float(gamma), pm, C.c_float(offset),
+    ret = np.zeros(n, _R) if first else np.array(returns, _R).reshape(n).copy()
+    reward = np.empty(n, _R)
+    lib().orc_disc_predict_reward(F, Hd, pp, px, n, _CR(gamma), pm, _CR(offset),
                                   _fp(ret), int(first), _fp(reward))
     return reward.reshape(n, 1), ret.reshape(n, 1)
 
@@ -363,10 +379,10 @@ def relabel(F, Hd, params, obs_feat, masks, gamma, offset, d_returns, rms_state)
     T, N = obs_feat.shape[0] - 1, obs_feat.shape[1]
     masks, pm = _f(masks)
     first = C.c_int(1 if d_returns is None else 0)
-    ret = np.zeros(N, np.float32) if d_returns is None else np.array(d_returns, np.float32).reshape(N).copy()
+    ret = np.zeros(N, _R) if d_returns is None else np.array(d_returns, _R).reshape(N).copy()
     st = (C.c_double * 3)(*rms_state)
-    rewards = np.empty((T, N), np.float32)
-    lib().orc_relabel(F, Hd, pp, T, N, pf, pm, C.c_float(gamma), C.c_float(offset), _fp(ret),
+    rewards = np.empty((T, N), _R)
+    lib().orc_relabel(F, Hd, pp, T, N, pf, pm, _CR(gamma), _CR(offset), _fp(ret),
                       C.byref(first), st, _fp(rewards))
     return rewards, ret, [st[0], st[1], st[2]]
 

@@ -91,6 +91,7 @@ PROTOTYPES = {
                                       C.c_int64, C.c_uint64, c_float_p, c_int_p]),
     "sg_disc_predict_reward": (C.c_int, [H, c_float_p, C.c_int, C.c_float, c_float_p, C.c_float, c_float_p, c_float_p]),
     "sg_disc_predict_prob": (C.c_int, [H, c_float_p, C.c_int, c_float_p]),
+    "sg_disc_predict_reward_steps": (C.c_int, [H, H, C.c_float, C.c_float, c_float_p, c_float_p]),
     "sg_disc_grad_pen": (C.c_int, [H, c_float_p, c_float_p, c_float_p, C.c_int, C.c_uint64, c_float_p]),
     "sg_disc_last_draws": (C.c_int, [H, c_i64_p, c_i64_p, c_float_p, c_i64_p]),
     "sg_disc_reset_returns": (C.c_int, [H]),

@@ -1,10 +1,15 @@
 """Discriminator -- host mirror of a2c/algo/gail.py:34-217 (GAIL-dyn variant)."""
 import ctypes as C
+import os
+import weakref
 
 import numpy as np
 
 from .. import _lib
 from ..utils import RunningMeanStd, derive_seed, to_host_tensor
+
+
+_PREFETCH = os.environ.get("SG_RELABEL_PREFETCH", "1") != "0"
 
 
 class _Trunk(object):
@@ -44,6 +49,8 @@ class Discriminator(object):
         self._calls = 0
         self.seed = derive_seed(seed, 0xD15C)   # DataLoader shuffle / feed_forward_generator / mixup-alpha streams
         self._ret_n = None
+        self._steps = None        # predict_reward_combined: the relabel loop's T steps computed by one launch, being served call by call
+        self._w_version = 0       # bumped by everything that changes the weights
         self._init_params(np.random.default_rng(seed))
 
     def __del__(self):
@@ -75,6 +82,7 @@ class Discriminator(object):
         return out
 
     def set_flat_params(self, flat):
+        self._weights_changing()
         flat = _lib.as_f32(flat).reshape(-1)
         _lib.check(self.lib.sg_disc_set_params(self.h, _lib.fptr(flat), flat.size))
 
@@ -89,6 +97,10 @@ class Discriminator(object):
         """Restore the optimizer state (torch.optim.Adam exp_avg / exp_avg_sq / step, a2c/algo/gail.py:48)."""
         m, v = _lib.as_f32(m).reshape(-1), _lib.as_f32(v).reshape(-1)
         _lib.check(self.lib.sg_disc_set_adam(self.h, _lib.fptr(m), _lib.fptr(v), m.size, int(step)))
+
+    def _weights_changing(self):
+        self._steps_retire()
+        self._w_version += 1
 
     def train(self, mode=True):
         return self
@@ -145,6 +157,7 @@ class Discriminator(object):
         expert_perm / policy_perm / alpha inject the reference's RNG artefacts (parity tests).
         fetch_losses=False: return None as soon as the epoch is queued on the device (a driver that keeps only the last
         epoch's losses, like a2c/main_gail_dyn_ppo.py:255-256, need not wait for the earlier ones)."""
+        self._weights_changing()
         B = self._bind_loader(expert_loader)
         rollouts._push([_lib.F_OBS_FEAT])
         out = (C.c_float * 3)()
@@ -167,6 +180,7 @@ class Discriminator(object):
         Not called by any shipped driver (a2c/main_gail_dyn_ppo.py:256 uses update_gail_dyn); same device
         step on rows assembled here: policy rows = (state | action), or for is_gail_dyn
         (obs_feat | obs[:, -a_dim:] | next_obs_feat) (a2c/algo/gail.py:102-109)."""
+        self._weights_changing()
         ds = expert_loader.dataset
         # the reference re-applies obsfilt (VecNormalize._obfilt with the CURRENT ob_rms) to every expert batch of every
         # call (a2c/algo/gail.py:118-120), so a filtered expert matrix is rebuilt per call; only the unfiltered one is cached
@@ -201,7 +215,19 @@ class Discriminator(object):
 
     # ---------------------------------------------------------------------- rewards
     def predict_reward_combined(self, d_in, gamma, masks, offset=0.0):
-        """a2c/algo/gail.py:201-210 -> (reward [n,1], returns [n,1]); self.returns persists."""
+        """a2c/algo/gail.py:201-210 -> (reward [n,1], returns [n,1]); self.returns persists.
+
+        The unchanged main calls this T times per update with `rollouts.obs_feat[step + 1]`, `rollouts.masks[step]`
+        (a2c/main_gail_dyn_ppo.py:275-280).  When the arguments ARE those slices of a drop-in rollout, the call for step 0 runs
+        all T steps in one launch (sg_disc_predict_reward_steps: same kernels, same rows, same recurrence) and the calls for
+        steps 1 .. T-1 are served from its result -- bit-identical to T separate calls, one upload and one read-back instead of
+        T of each.  Anything that is not that pattern (other rows, another order, a changed mask / obs_feat / weight / gamma /
+        offset / Discriminator.returns in between) takes the per-call path from the state the served calls imply.
+        SG_RELABEL_PREFETCH=0 turns the recognition off."""
+        hit = self._steps_lookup(d_in, gamma, masks, offset)
+        if hit is not None:
+            return hit
+        self._steps_retire()
         x = _lib.as_f32(d_in).reshape(-1, self.input_dim)
         n = x.shape[0]
         m = _lib.as_f32(masks).reshape(-1)
@@ -214,6 +240,56 @@ class Discriminator(object):
                                                    float(offset), _lib.fptr(reward), _lib.fptr(returns)))
         self._ret_n = n
         return to_host_tensor(reward), to_host_tensor(returns)
+
+    # -- the relabel loop's T calls from one launch ------------------------------------------------------------------------
+    def _steps_slice(self, d_in, masks):
+        """(rollout, step) when (d_in, masks) are exactly rollouts.obs_feat[step + 1] / rollouts.masks[step] of a drop-in rollout."""
+        from ..storage import rollout_of_feat_slice
+        ro = rollout_of_feat_slice(d_in)
+        if ro is None or ro.device_resident or ro.feat_len != self.input_dim or getattr(masks, "_base", None) is not ro.masks:
+            return None
+        N, F = ro.num_processes, ro.feat_len
+        off = d_in.storage_offset()
+        if tuple(d_in.shape) != (N, F) or not d_in.is_contiguous() or off % (N * F) or tuple(masks.shape) != (N, 1) or not masks.is_contiguous():
+            return None
+        step = off // (N * F) - 1
+        if step < 0 or step >= ro.num_steps or masks.storage_offset() != step * N:
+            return None
+        return ro, step
+
+    def _steps_lookup(self, d_in, gamma, masks, offset):
+        if not _PREFETCH or not hasattr(d_in, "storage_offset") or not hasattr(masks, "storage_offset"):
+            return None
+        hit = self._steps_slice(d_in, masks)
+        if hit is None:
+            return None
+        ro, step = hit
+        c = self._steps
+        key = (float(gamma), float(offset), self._w_version, ro.obs_feat._version, ro.masks._version)
+        if step == 0:
+            self._steps_retire()
+            if self._ret_n and self._ret_n != ro.num_processes and self.returns is not None:
+                return None                                   # (the per-call path raises the reference's size error)
+            T, N = ro.num_steps, ro.num_processes
+            ro._push([_lib.F_OBS_FEAT, _lib.F_MASKS])
+            reward, returns = np.empty((T, N, 1), np.float32), np.empty((T, N, 1), np.float32)
+            _lib.check(self.lib.sg_disc_predict_reward_steps(self.h, ro.h, float(gamma), float(offset), _lib.fptr(reward), _lib.fptr(returns)))
+            self._ret_n = N
+            c = self._steps = {"ro": weakref.ref(ro), "key": key, "reward": reward, "returns": returns, "pos": -1, "T": T}
+        elif c is None or c["ro"]() is not ro or c["key"] != key or step != c["pos"] + 1:
+            return None
+        c["pos"] = step
+        out = to_host_tensor(c["reward"][step].copy()), to_host_tensor(c["returns"][step].copy())
+        if step == c["T"] - 1:
+            self._steps = None                                # complete: the device's returns ARE the state after the T-th call
+        return out
+
+    def _steps_retire(self):
+        """Leave the served-from-cache mode: Discriminator.returns on the device becomes what the calls served so far imply."""
+        c, self._steps = self._steps, None
+        if c is not None and 0 <= c["pos"] < c["T"] - 1:
+            v = np.ascontiguousarray(c["returns"][c["pos"]].reshape(-1))
+            _lib.check(self.lib.sg_disc_set_returns(self.h, _lib.fptr(v), v.size))
 
     def predict_reward(self, state, action, gamma, masks, offset=0.0):
         """a2c/algo/gail.py:195-199"""
@@ -269,6 +345,9 @@ class Discriminator(object):
 
     @property
     def returns(self):
+        c = self._steps
+        if c is not None and 0 <= c["pos"] < c["T"] - 1:      # mid-loop: the state after the calls served so far
+            return to_host_tensor(c["returns"][c["pos"]].copy())
         none = C.c_int(0)
         _lib.check(self.lib.sg_disc_get_returns(self.h, None, 0, C.byref(none)))
         if none.value:
@@ -283,6 +362,7 @@ class Discriminator(object):
 
     @returns.setter
     def returns(self, value):
+        self._steps = None        # whatever was being served is void: the caller sets the state
         if value is None:
             _lib.check(self.lib.sg_disc_reset_returns(self.h))
             self._ret_n = None
@@ -296,6 +376,7 @@ class Discriminator(object):
         device's own done count, the fused relabel, ret_rms kept inside the library (`set_rms` / `scalars`).  Device-resident
         rollouts only (the rewards stay in HBM)."""
         assert rollouts.device_resident, "relabel_rewards_auto leaves the rewards on the device"
+        self._steps_retire()
         _lib.check(self.lib.sg_disc_relabel_rewards_auto(self.h, rollouts.h, float(gamma), float(gail_tar_length),
                                                          1 if no_alive_bonus else 0))
         self._ret_n = rollouts.num_processes
@@ -313,6 +394,7 @@ class Discriminator(object):
     def relabel_rewards(self, rollouts, gamma, offset, ret_rms):
         """Fused a2c/main_gail_dyn_ppo.py:275-292 over all T steps on device; ret_rms is the caller's
         RunningMeanStd (float64 state updated in place); rollouts.rewards is rewritten."""
+        self._steps_retire()
         rollouts._push([_lib.F_OBS_FEAT, _lib.F_MASKS])
         st = (C.c_double * 3)(*ret_rms.get_state())
         _lib.check(self.lib.sg_disc_relabel_rewards(self.h, rollouts.h, float(gamma), float(offset), st))

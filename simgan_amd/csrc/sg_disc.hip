@@ -883,6 +883,33 @@ extern "C" int sg_disc_predict_reward(sg_disc* d, const float* x, int n, float g
     return 0;
 }
 
+// The unchanged main's relabel loop (a2c/main_gail_dyn_ppo.py:275-280) makes T calls of predict_reward_combined(obs_feat[t + 1],
+// gamma, masks[t], offset), each an upload, a launch pair and two read-backs.  This is all T of them in one pass over the rollout's
+// device copy: the same forward kernel on the same rows and the same recurrence in the same order (k_returns_scan's body is
+// k_returns_step's), so reward[t] / returns[t] are bit for bit what the t-th call returns; Discriminator.returns ends where the
+// T-th call leaves it.
+extern "C" int sg_disc_predict_reward_steps(sg_disc* d, sg_rollout* r, float gamma, float offset, float* reward, float* returns) {
+    SG_REQUIRE(d && r && reward && returns, "sg_disc_predict_reward_steps: NULL argument");
+    SG_REQUIRE(r->F == d->desc.F, "sg_disc_predict_reward_steps: rollout feat_len %d != discriminator input_dim %d", r->F, d->desc.F);
+    sg_ctx* ctx = d->ctx;
+    SG_CHECK(hipSetDevice(ctx->device));
+    const int T = r->T, N = r->N;
+    const size_t TN = (size_t)T * N;
+    SG_TRY(ensure_returns(d, N));
+    float* scratch = nullptr;
+    SG_TRY(sg_ctx_scratch(ctx, sizeof(float) * 2 * TN, &scratch));
+    float *raw = scratch, *rets = scratch + TN;
+    SG_TRY(disc_forward_dev(d, r->d_field[SG_F_OBS_FEAT] + (size_t)N * r->F, (int)TN, offset, raw));
+    hipLaunchKernelGGL(k_returns_scan, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, d->d_returns, raw, r->d_field[SG_F_MASKS], gamma,
+                       d->returns_none ? 1 : 0, T, N, rets);
+    SG_CHECK(hipGetLastError());
+    d->returns_none = false;
+    SG_CHECK(hipMemcpyAsync(reward, raw, sizeof(float) * TN, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipMemcpyAsync(returns, rets, sizeof(float) * TN, hipMemcpyDeviceToHost, ctx->stream));
+    SG_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 extern "C" int sg_disc_grad_pen(sg_disc* d, const float* expert_rows, const float* policy_rows, const float* alpha, int n,
                                 uint64_t seed, float* pen) {
     SG_REQUIRE(d && expert_rows && policy_rows && pen && n > 0, "sg_disc_grad_pen: bad argument");

@@ -199,3 +199,149 @@ def test_verify_mode_catches_a_write_behind_torchs_back(sg, orc, monkeypatch):
     ro.mark_host_written()
     ro.compute_returns(nv, True, 0.99, 0.95, True)
     assert_close(ro.returns.numpy()[:T, :, 0], _oracle_returns(orc, ro, nv)[:T], rtol=1e-5, what="returns after mark_host_written")
+
+
+def _relabel_problem(sg, seed=11, T=12, N=16, F=9, Hd=16):
+    rng = np.random.default_rng(seed)
+    D = sg.algo.gail.Discriminator(F, Hd, None, seed=3)
+    ro = sg.RolloutStorage(T, N, (4,), Box((2,)), 1, F)
+    ro.obs_feat.copy_(ro.obs_feat.new_tensor(rng.standard_normal((T + 1, N, F)).astype(np.float32)))
+    ro.masks.copy_(ro.masks.new_tensor((rng.random((T + 1, N, 1)) > 0.2).astype(np.float32)))
+    return D, ro, rng
+
+
+def _loop(D, ro, steps, gamma=0.97, offset=0.3):
+    """The main's relabel loop (a2c/main_gail_dyn_ppo.py:275-280), returning every call's (reward, returns)."""
+    out = []
+    for step in steps:
+        rew, ret = D.predict_reward_combined(ro.obs_feat[step + 1], gamma, ro.masks[step], offset=offset)
+        ro.rewards[step] = rew
+        out.append((rew.numpy().copy(), ret.numpy().copy()))
+    return out
+
+
+def _calls(D):
+    """(per-call launches, fused launches) so far, read off the ctypes entry points through a counting shim."""
+    return D._n_single, D._n_steps
+
+
+def _counting(D):
+    lib = D.lib
+    D._n_single = D._n_steps = 0
+
+    class Counting(object):
+        def __getattr__(self, name):
+            f = getattr(lib, name)
+            if name == "sg_disc_predict_reward":
+                def g(*a):
+                    D._n_single += 1
+                    return f(*a)
+                return g
+            if name == "sg_disc_predict_reward_steps":
+                def g(*a):
+                    D._n_steps += 1
+                    return f(*a)
+                return g
+            return f
+
+    D.lib = Counting()
+    return D
+
+
+def test_the_mains_relabel_loop_is_one_launch_and_bit_identical_to_T_calls(sg, monkeypatch):
+    """a2c/main_gail_dyn_ppo.py:275-280 through the unchanged call: the call for step 0 computes all T steps
+    (sg_disc_predict_reward_steps), steps 1 .. T-1 are served from it -- every (reward, returns) pair, Discriminator.returns
+    after every call and at the end EQUAL what T separate launches give; over two consecutive loops (the second continues
+    Discriminator.returns), with a discriminator update in between."""
+    from simgan_amd.algo import gail
+    D, ro, rng = _relabel_problem(sg)
+    T, N = ro.num_steps, ro.num_processes
+    p0 = D.get_flat_params()
+    expert = rng.standard_normal((64, 9)).astype(np.float32)
+
+    class Loader:
+        def __init__(self, e, b):
+            self.expert, self.batch_size = e, b
+
+    def run(prefetch):
+        monkeypatch.setattr(gail, "_PREFETCH", prefetch)
+        D.set_flat_params(p0)
+        D.set_adam(np.zeros_like(p0), np.zeros_like(p0), 0)
+        D.returns = None
+        _counting(D)
+        res, mid = [], []
+        for it in range(2):
+            for step in range(T):
+                res += _loop(D, ro, [step])
+                mid.append(D.returns.numpy().copy())            # read mid-loop: the state after the calls made so far
+            D.update_gail_dyn(Loader(expert, 16), ro, expert_perm=np.arange(64), policy_perm=np.arange(T * N), alpha=np.full(64, 0.5, np.float32))
+        counts = _calls(D)
+        D.lib = D.ctx.lib
+        return res, mid, counts, D.returns.numpy().copy()
+
+    fast, fast_mid, fast_counts, fast_end = run(True)
+    slow, slow_mid, slow_counts, slow_end = run(False)
+    assert fast_counts == (0, 2) and slow_counts == (2 * T, 0), (fast_counts, slow_counts)
+    for k, ((ra, ta), (rb, tb)) in enumerate(zip(fast, slow)):
+        assert np.array_equal(ra, rb) and np.array_equal(ta, tb), f"call {k}: served from the fused launch != its own launch"
+    for a_, b_ in zip(fast_mid, slow_mid):
+        assert np.array_equal(a_, b_)
+    assert np.array_equal(fast_end, slow_end)
+
+
+@pytest.mark.parametrize("case", ["foreign_rows", "mask_edit", "feat_edit", "gamma_change", "offset_change", "out_of_order", "weights_change",
+                                  "returns_assigned", "starts_late", "resident"])
+def test_relabel_loop_cache_misses_fall_back_to_the_per_call_path(sg, monkeypatch, case):
+    """Everything that is not the main's pattern must give exactly what per-call launches give: the served-from-cache state
+    is committed (Discriminator.returns after the calls served so far) and the call takes its own launch."""
+    from simgan_amd.algo import gail
+    T = 12
+
+    def scenario(D, ro, rng_):
+        out = _loop(D, ro, range(4))
+        if case == "foreign_rows":
+            x = rng_.standard_normal((ro.num_processes, 9)).astype(np.float32)
+            rew, ret = D.predict_reward_combined(x, 0.97, ro.masks[4], offset=0.3)
+            out.append((rew.numpy().copy(), ret.numpy().copy()))
+            out += _loop(D, ro, range(5, T))
+        elif case == "mask_edit":
+            ro.masks[6] = ro.masks[6] * 0.0
+            out += _loop(D, ro, range(4, T))
+        elif case == "feat_edit":
+            ro.obs_feat[8] = ro.obs_feat[8] + 1.0
+            out += _loop(D, ro, range(4, T))
+        elif case == "gamma_change":
+            out += _loop(D, ro, range(4, T), gamma=0.9)
+        elif case == "offset_change":
+            out += _loop(D, ro, range(4, T), offset=-0.1)
+        elif case == "out_of_order":
+            out += _loop(D, ro, [6, 5, 4, 7, 8])
+        elif case == "weights_change":
+            D.set_flat_params(D.get_flat_params() * np.float32(1.01))
+            out += _loop(D, ro, range(4, T))
+        elif case == "returns_assigned":
+            D.returns = np.full((ro.num_processes, 1), 0.25, np.float32)
+            out += _loop(D, ro, range(4, T))
+        elif case == "starts_late":
+            out += _loop(D, ro, range(4, T))
+            D.returns = None
+            out += _loop(D, ro, range(3, T))                     # a loop that does not start at step 0: never prefetched
+        elif case == "resident":
+            out += _loop(D, ro, range(4, T))
+            ro.sync_to_device()
+            ro.device_resident = True                            # host slices are then not what the device holds: per-call path
+            out += _loop(D, ro, range(0, T))
+        out.append((D.returns.numpy().copy(), D.returns.numpy().copy()))
+        return out
+
+    results = []
+    for prefetch in (True, False):
+        monkeypatch.setattr(gail, "_PREFETCH", prefetch)
+        D, ro, rng = _relabel_problem(sg)
+        _counting(D)
+        results.append((scenario(D, ro, np.random.default_rng(5)), _calls(D)))
+    (fast, fc), (slow, sc) = results
+    assert fc[1] >= 1 and sc[1] == 0, (fc, sc)
+    assert len(fast) == len(slow)
+    for k, ((ra, ta), (rb, tb)) in enumerate(zip(fast, slow)):
+        assert np.array_equal(ra, rb) and np.array_equal(ta, tb), f"{case}: call {k} differs between the cached and the per-call path"

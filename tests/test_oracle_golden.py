@@ -324,3 +324,39 @@ def test_fast_cpu_discriminator_gradient_equals_the_oracle(F, Hd, nb):
     G1, s1 = orc.disc_grad_rows_fast(F, Hd, par, e, p, al, 1.0 / nb)
     assert_close(s1, s0, what="loss sums")
     assert np.abs(G1 - G0).max() <= 1e-4 * np.abs(G0).max() + 1e-7, (np.abs(G1 - G0).max(), np.abs(G0).max())
+
+
+# ------------------------------------------------------------------------------------------ the float64 arbiter
+# oracle/sg_oracle_f64.c is the oracle's source with float := double.  It is NOT a parity oracle (the reference computes in
+# float32); these tests only establish that it is the same algorithm -- it reproduces the reference's captures to float32
+# round-off -- so that tools/parity_f64.py may use it as the point both float32 evaluations are measured from.
+@pytest.mark.parametrize("name", ["ppo_mlp_northstar", "ppo_split_hopper"])
+def test_float64_arbiter_runs_the_same_ppo_update(name):
+    from oracle import oracle64 as o64
+    g = load(name)
+    m = g["meta"]
+    d = o64.dims(KIND[m["kind"]], m["O"], m["A"], m["H"], m["num_feet"])
+    cfg = o64.ppo_cfg(m["clip_param"], m["ppo_epoch"], m["num_mini_batch"], m["value_loss_coef"], m["entropy_coef"], m["lr"], m["eps"],
+                      m["max_grad_norm"], True)
+    params = g["params0"].astype(np.float64)
+    adam = o64.AdamState(params.size)
+    assert adam.m.dtype == np.float64
+    losses = o64.ppo_update(d, params, adam, cfg, g["obs"], g["actions"], g["value_preds"][..., 0], g["returns"][..., 0],
+                            g["action_log_probs"][..., 0], g["perms"])
+    assert_close(losses, g["losses"], what="ppo losses (float64)")
+    assert_close(params, g["params1"], what="params after update (float64)")
+
+
+@pytest.mark.parametrize("name", ["disc_northstar", "disc_hopper"])
+def test_float64_arbiter_runs_the_same_discriminator_epochs(name):
+    from oracle import oracle64 as o64
+    g = load(name)
+    m = g["meta"]
+    params = g["params0"].astype(np.float64)
+    adam = o64.AdamState(params.size)
+    for ep in range(m["epochs"]):
+        losses, n_d = o64.disc_update(m["F"], m["Hd"], params, adam, g["expert"], g["obs_feat"], m["B"],
+                                      g[f"expert_perm{ep}"], g[f"policy_perm{ep}"], g[f"alpha{ep}"])
+        assert n_d == int(g[f"n_steps{ep}"])
+        assert_close(losses, g[f"losses{ep}"], what=f"disc losses ep{ep} (float64)")
+        assert_close(params, g[f"params_after{ep}"], what=f"disc params ep{ep} (float64)")
