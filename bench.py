@@ -421,27 +421,47 @@ def dropin_leg(sg, _lib, ctx, w, updates=5):
     pol, disc, agent, ro, loader, learner = fresh()
     ret_rms = RunningMeanStd(shape=())
 
+    split = {"d_epochs": 0.0, "relabel_loop": 0.0, "relabel_loop_library": 0.0, "returns_ppo_after": 0.0, "n": 0}
+    real_prc = disc.predict_reward_combined
+
+    def timed_prc(*a_, **k_):       # the library's share of the relabel loop (the rest of the loop is the main's own numpy / torch code)
+        t_ = time.perf_counter()
+        out_ = real_prc(*a_, **k_)
+        split["relabel_loop_library"] += time.perf_counter() - t_
+        return out_
+
+    disc.predict_reward_combined = timed_prc
+
     def main_iteration():
+        t_a = time.perf_counter()
         with torch.no_grad():
             next_value = pol.get_value(ro.obs[-1], ro.recurrent_hidden_states[-1], ro.masks[-1]).detach()
         for _ in range(w["E_d"]):
             gail_loss, gail_loss_e, gail_loss_p = disc.update_gail_dyn(loader, ro)
         num_of_dones = float((1.0 - ro.masks).sum().cpu().numpy())
         r_sa = alive_bonus_offset(num_of_dones, T, N, 500.0)
+        t_b = time.perf_counter()
         for step in range(T):
             ro.rewards[step], returns = disc.predict_reward_combined(ro.obs_feat[step + 1], GAMMA, ro.masks[step], offset=-r_sa)
             ret_rms.update(returns.view(-1).cpu().numpy())
             rews = ro.rewards[step].view(-1).cpu().numpy()
             rews = np.clip(rews / np.sqrt(ret_rms.var + 1e-7), -10.0, 10.0)
             ro.rewards[step] = torch.Tensor(rews).view(-1, 1)
+        t_c = time.perf_counter()
         ro.compute_returns(next_value, True, GAMMA, LAM, True)
         out = agent.update(ro)
         ro.after_update()
+        t_d = time.perf_counter()
+        split["d_epochs"] += t_b - t_a
+        split["relabel_loop"] += t_c - t_b
+        split["returns_ppo_after"] += t_d - t_c
+        split["n"] += 1
         return out
 
-    def timed_host(fn):
-        fn()
-        fn()
+    def timed_host(fn, prewarmed=False):
+        if not prewarmed:
+            fn()
+            fn()
         ctx.synchronize()
         per, b0 = [], ro.bytes_uploaded
         for _ in range(updates):
@@ -452,9 +472,20 @@ def dropin_leg(sg, _lib, ctx, w, updates=5):
             per.append(1e3 * (time.perf_counter() - t0))
         return sum(per) / len(per) * 1e-3, per, (ro.bytes_uploaded - b0) // updates
 
-    dt, per, up = timed_host(main_iteration)
+    def timed_host_main():
+        main_iteration()
+        main_iteration()
+        for k_ in split:
+            split[k_] = 0.0 if k_ != "n" else 0
+        return timed_host(main_iteration, prewarmed=True)
+
+    dt, per, up = timed_host_main()
     res["literal_main"] = {"ms_per_step": round(1e3 * dt, 3), "env_steps_s": round(T * N / dt, 1), "min_ms": round(min(per), 3), "max_ms": round(max(per), 3),
                            "bytes_uploaded_per_update": up,
+                           # where the host's wall clock goes (ms per update): 5 synchronous D epochs (+ get_value, done count) | the T-step
+                           # relabel loop, of which inside the library (ONE fused launch on step 0, T - 1 calls served from its result) --
+                           # the remainder is the main's own per-step numpy / torch code | compute_returns + agent.update + after_update
+                           "split_ms": {k_: round(1e3 * v_ / max(split["n"], 1), 3) for k_, v_ in split.items() if k_ != "n"},
                            "sequence": f"{w['E_d']} x update_gail_dyn, {T} x (predict_reward_combined + ret_rms.update + clip), compute_returns, agent.update, after_update"}
     # the bare upload of one rollout (every field once)
     ctx.synchronize()

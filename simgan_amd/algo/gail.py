@@ -279,7 +279,8 @@ class Discriminator(object):
         elif c is None or c["ro"]() is not ro or c["key"] != key or step != c["pos"] + 1:
             return None
         c["pos"] = step
-        out = to_host_tensor(c["reward"][step].copy()), to_host_tensor(c["returns"][step].copy())
+        # (no copies: each row is handed out once; `returns` aliases the member in the reference too -- a2c/algo/gail.py:210 returns self.returns)
+        out = to_host_tensor(c["reward"][step]), to_host_tensor(c["returns"][step])
         if step == c["T"] - 1:
             self._steps = None                                # complete: the device's returns ARE the state after the T-th call
         return out
