@@ -239,7 +239,6 @@ struct sg_ppo {
     sg_policy* policy;
     sg_ppo_config cfg;
     float *d_m = nullptr, *d_v = nullptr, *d_grad = nullptr;
-    float* d_alt = nullptr;        // the two-launch step's second buffer set: params | m | v (each `total` floats), see sg_ppo_update
     float* d_slabs = nullptr;      // [row groups][total+8] partial bias-type gradients and loss sums
     size_t slabs_cap = 0;
     float* d_stacks = nullptr;     // row stacks of one minibatch (activations / their gradients)

@@ -180,7 +180,7 @@ extern "C" int sg_ppo_destroy(sg_ppo* a) {
     (void)hipStreamSynchronize(a->ctx->stream);
     sg_ctx_learner_gone(a->ctx);
     for (auto& q : a->ctx->res_a) if (q == a) q = nullptr;
-    float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks, a->d_alt};
+    float* ptrs[] = {a->d_m, a->d_v, a->d_grad, a->d_slabs, a->d_state, a->d_part, a->d_stacks};
     for (float* q : ptrs) if (q) (void)sg_dev_free(q);
     if (a->d_perms) (void)sg_dev_free(a->d_perms);
     if (a->d_loss_acc) (void)sg_dev_free(a->d_loss_acc);
@@ -420,9 +420,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     pa.slabs = a->d_slabs; pa.slab_stride = slab_stride; pa.ldP = ldP; pa.dbg = a->d_dbg;
     pa.st = reinterpret_cast<SgOptState*>(a->d_state); pa.G = G; pa.k1 = 0;
     pa.pair = a->d_pair;
-    pa.lz_grad = pa.lz_part = pa.lz_m = pa.lz_v = nullptr;
-    pa.lz_params_out = pa.lz_m_out = pa.lz_v_out = nullptr;
-    pa.lz_npart = 0; pa.lz_eps = 0.f; pa.lz_max_norm = 0.f;
     for (int t = 0; t < 3; ++t) {
         const bool on = t < d.n_trunks;
         pa.H1[t] = on ? stk : nullptr; if (on) stk += (size_t)mbp * d.ldH;
@@ -450,16 +447,6 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     if (pair && !a->pair_primed) SG_CHECK(hipMemsetAsync(a->d_stacks, 0, sizeof(float) * (epoch_f + stack_f), ctx->stream));
     a->pair_primed = pair;
     const size_t lds_f = ppo_fwd_lds(d, MT, gw), lds_b = ppo_bwd_lds(d, MT, gw);
-    // Policy on one GPU: the step as TWO launches.  k_ppo_adam (4.4 us, launch-bound: 15 k parameters) is not launched; the Adam
-    // of step k is applied by the workgroups of step k + 1's k_ppo_bwd to their own trunk's block on its way into LDS -- the
-    // block, both moments and the reduced gradient are four loads instead of one, the arithmetic is k_ppo_adam's element for
-    // element -- and row group 0 of each trunk writes the updated block and moments to the OTHER buffer set (a launch reads one
-    // set and writes the other: no workgroup can see a half-updated vector).  k_ppo_reduce takes over the loss sums and the next
-    // step's bias corrections; the update's last step ends with one k_ppo_adam from whichever set is current into the canonical
-    // one.  Bit-identical to the three-launch step (tests/test_gpu_fullsize.py).  SG_PPO_LAZY=0: three launches.
-    const char* lzenv = getenv("SG_PPO_LAZY");
-    const bool lazy = fused && !gw && !ctx->use_comm && !owned && !(lzenv && !strcmp(lzenv, "0"));
-    if (lazy && !a->d_alt) SG_CHECK(sg_dev_malloc((void**)&a->d_alt, sizeof(float) * 3 * (size_t)d.total));
     const int nblk = (d.total + 8 + 255) / 256;
     const int nblk_r = (d.total + 8 + SG_PPO_REDUCE_PARAMS - 1) / SG_PPO_REDUCE_PARAMS;
     SgOptState* st = reinterpret_cast<SgOptState*>(a->d_state);
@@ -467,12 +454,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
     // The E*M optimizer steps (+ one row gather per epoch) depend only on buffer addresses, the minibatch geometry
     // and the PPO coefficients: the learning rate and Adam's step count live on the device.  The sequence is
     // captured into a hipGraph once and replayed per update, so the host issues one call instead of ~650.
-    float* const set_p[2] = {a->policy->d_params, a->d_alt};
-    float* const set_m[2] = {a->d_m, a->d_alt ? a->d_alt + d.total : nullptr};
-    float* const set_v[2] = {a->d_v, a->d_alt ? a->d_alt + 2 * (size_t)d.total : nullptr};
     auto enqueue_steps = [&]() -> int {
-        int cur = 0;
-        bool pending = false;
         hipLaunchKernelGGL(k_opt_prepare_first, dim3(1), dim3(1), 0, ctx->stream, st);
         for (int e = 0; e < E; ++e) {
             ga.perm = a->d_perms + (size_t)e * TN;
@@ -497,37 +479,19 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                         launch_ppo_fwd(ctx, MT, d, dim3(G, d.n_trunks), lds_f, pa, gw);
                     }
                     pa.wbuf_floats = fused ? wb_f : wb_b;
-                    if (lazy) {
-                        pa.params = set_p[cur];
-                        pa.lz_grad = pending ? a->d_grad : nullptr;
-                        pa.lz_part = a->d_part; pa.lz_npart = nblk_r;
-                        pa.lz_m = set_m[cur]; pa.lz_v = set_v[cur];
-                        pa.lz_params_out = set_p[cur ^ 1]; pa.lz_m_out = set_m[cur ^ 1]; pa.lz_v_out = set_v[cur ^ 1];
-                        pa.lz_eps = a->cfg.eps; pa.lz_max_norm = a->cfg.max_grad_norm;
-                    }
                     launch_ppo_bwd(ctx, MT, d, dim3(G, d.n_trunks), lds_b, pa, fused, gw);
-                    if (lazy && pending) cur ^= 1;
-                }
-                if (lazy) {
-                    SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
-                              d.total, a->d_grad, a->d_part, st, e * M + k + 1, pa.inv_B, a->d_loss_acc);
-                    pending = true;
-                    continue;
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_REDUCE, k_ppo_reduce, dim3(nblk_r), dim3(256), 0, a->d_slabs, G, slab_stride,
-                          d.total, a->d_grad, a->d_part, (SgOptState*)nullptr, 0, 0.f, (double*)nullptr);
+                          d.total, a->d_grad, a->d_part);
                 if (ctx->use_comm) {
                     SG_TRY(sg_comm_allreduce_f32(ctx, a->d_grad, d.total + 8));
                     hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, a->d_grad, d.total, a->d_part);
                 }
                 SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, a->policy->d_params, a->d_m, a->d_v,
                           a->d_grad, a->d_part, ctx->use_comm ? nblk : nblk_r, d.total, st, e * M + k + 1, a->cfg.eps, a->cfg.max_grad_norm,
-                          pa.inv_B, a->d_loss_acc, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                          pa.inv_B, a->d_loss_acc);
             }
         }
-        if (lazy && pending)   // the last step's Adam: from the current set into the canonical one
-            SG_LAUNCH(ctx, SG_PROF_PPO_ADAM, k_ppo_adam, dim3(nblk), dim3(256), 0, set_p[cur], set_m[cur], set_v[cur], a->d_grad, a->d_part,
-                      nblk_r, d.total, st, E * M, a->cfg.eps, a->cfg.max_grad_norm, pa.inv_B, (double*)nullptr, set_p[0], set_m[0], set_v[0]);
         hipLaunchKernelGGL(k_opt_commit, dim3(1), dim3(1), 0, ctx->stream, st, E * M);
         return 0;
     };
@@ -548,7 +512,7 @@ extern "C" int sg_ppo_update(sg_ppo* a, sg_rollout* r, const int64_t* perms, int
                                   (uint64_t)TN, ((uint64_t)E << 32) | (uint64_t)M, ((uint64_t)MT << 32) | (uint64_t)G,
                                   ((uint64_t)fbits[0] << 32) | fbits[1], ((uint64_t)fbits[2] << 32) | fbits[3],
                                   ((uint64_t)fbits[4] << 32) | fbits[5], (uint64_t)a->cfg.use_clipped_value_loss,
-                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0) + (sg_comm_peer_on(ctx) ? 32 : 0) + (lazy ? 64 : 0) + ((uint64_t)sg_comm_peer_generation(ctx) << 32)};
+                                  (uint64_t)(uintptr_t)r->d_field[SG_F_LOGP], 0x50504full + (fused ? 1 : 0) + (ctx->use_comm ? 2 : 0) + (crit_first ? 4 : 0) + (gw ? 8 : 0) + (pair ? 16 : 0) + (sg_comm_peer_on(ctx) ? 32 : 0) + ((uint64_t)sg_comm_peer_generation(ctx) << 32)};
         if (!a->steps_graph || memcmp(key, a->steps_graph_key, sizeof key) != 0) {
             if (a->steps_graph) { SG_CHECK(hipGraphExecDestroy(a->steps_graph)); a->steps_graph = nullptr; }
             if (sg_try_capture(ctx, &a->steps_graph, enqueue_steps) != 0) {

@@ -46,15 +46,6 @@ struct PpoArgs {
     SgOptState* st;       // optimizer scalars (read by k_ppo_adam; prepared one step ahead by the previous k_ppo_adam)
     int k1, G;            // 1-based step index within the update; row groups
     unsigned* pair;       // k_ppo_pair: the error word an actor workgroup raises when its partner never shows up
-    // Adam of the PREVIOUS step applied on the way in (FUSED Policy, one GPU: the step is two launches, k_ppo_bwd + k_ppo_reduce).
-    // lz_grad == NULL: `params` are current.  Else `params` / lz_m / lz_v are the state BEFORE the previous step's Adam, lz_grad /
-    // lz_part its reduced gradient and per-block sums of squares (k_ppo_reduce); every workgroup forms the updated block of its
-    // trunk in registers on the way into LDS -- k_ppo_adam's arithmetic, element for element -- and row group 0 of each trunk
-    // also writes block and moments to the other buffer set (lz_*_out), which the next launch reads.
-    const float *lz_grad, *lz_part, *lz_m, *lz_v;
-    float *lz_params_out, *lz_m_out, *lz_v_out;
-    int lz_npart;
-    float lz_eps, lz_max_norm;
 };
 
 // k_ppo_pair (SplitPolicy, one launch per step): the two actor workgroups of a row group exchange their head outputs
@@ -234,17 +225,6 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
     // every global load of the block is issued before the first LDS store: one memory round trip, not six
     float4 wv[12];
     if (!GW) sg_stage_issue<12>(wv, a.params + tr.off + w_first, wfl / 4);
-    constexpr bool CAN_LAZY = FUSED && !GW && !PAIR;
-    constexpr int UL = CAN_LAZY ? 8 : 1;         // float4 per thread and array held in registers; the rest of a larger trunk goes through a loop
-    float4 lg[UL], lm[UL], lv[UL];
-    float lz_sum = 0.f;
-    const bool lazy = CAN_LAZY && a.lz_grad != nullptr;
-    if (CAN_LAZY && lazy) {
-        sg_stage_issue<UL>(lg, a.lz_grad + tr.off, wfl / 4);
-        sg_stage_issue<UL>(lm, a.lz_m + tr.off, wfl / 4);
-        sg_stage_issue<UL>(lv, a.lz_v + tr.off, wfl / 4);
-        if (tid < 256) for (int j = tid; j < a.lz_npart; j += 256) lz_sum += a.lz_part[j];   // k_ppo_adam's partition of the partials
-    }
     constexpr int UX = MT <= 2 ? 4 : 8;          // float4 per thread for an [R][ld <= 116] tile at 256 threads
     constexpr int UO = MT <= 2 ? 2 : 4;          // ... for an [R][ldP <= 64] tile
     const int ta = critic ? t : 0;
@@ -290,48 +270,7 @@ __device__ __forceinline__ void sg_ppo_bwd_body(const PpoArgs& a, const int t, c
         for (int q = 0; q < 4; ++q) SC[q * R + tid] = scv[q];
     }
     SG_PPO_STAMP(0);
-    if (CAN_LAZY && lazy) {
-        // ---- the previous step's clip_grad_norm_ + Adam (a2c/algo/ppo.py:143-145), k_ppo_adam's arithmetic in k_ppo_adam's order
-        __shared__ float lz_ws[4];
-        lz_sum = sg_wave_sum(lz_sum);
-        if (tid < 256 && (tid & 63) == 0) lz_ws[tid >> 6] = lz_sum;
-        __syncthreads();
-        const float norm = sqrtf((lz_ws[0] + lz_ws[1]) + (lz_ws[2] + lz_ws[3]));
-        float coef = a.lz_max_norm / (norm + 1e-6f);
-        coef = coef > 1.f ? 1.f : coef;
-        const int tstep = a.st->t0 + a.k1 - 1;     // the step whose gradient this is
-        const float step_size = a.st->step_size2[tstep & 1], bc2_sqrt = a.st->bc2_sqrt2[tstep & 1], eps = a.lz_eps;
-        const bool writer = bx == 0;
-        const int n4 = wfl / 4;
-        float4* dstW = reinterpret_cast<float4*>(Wimg);
-        float4* oP = reinterpret_cast<float4*>(a.lz_params_out + tr.off);
-        float4* oM = reinterpret_cast<float4*>(a.lz_m_out + tr.off);
-        float4* oV = reinterpret_cast<float4*>(a.lz_v_out + tr.off);
-        auto adam1 = [&](float& w, float gr, float& mi, float& vi) {
-            const float g = gr * coef;
-            mi = mi + (g - mi) * (float)(1.0 - 0.9);
-            vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
-            const float denom = sqrtf(vi) / bc2_sqrt + eps;
-            w = w - step_size * (mi / denom);
-        };
-        auto adam4 = [&](float4 w, const float4& g, float4 m, float4 v, int i) {
-            adam1(w.x, g.x, m.x, v.x); adam1(w.y, g.y, m.y, v.y); adam1(w.z, g.z, m.z, v.z); adam1(w.w, g.w, m.w, v.w);
-            dstW[i] = w;
-            if (writer) { oP[i] = w; oM[i] = m; oV[i] = v; }
-        };
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const int i = tid + u * (int)blockDim.x;
-            if (i < n4) adam4(wv[u], lg[u], lm[u], lv[u], i);
-        }
-        const float4* gP = reinterpret_cast<const float4*>(a.params + tr.off);
-        const float4* gG = reinterpret_cast<const float4*>(a.lz_grad + tr.off);
-        const float4* gM = reinterpret_cast<const float4*>(a.lz_m + tr.off);
-        const float4* gV = reinterpret_cast<const float4*>(a.lz_v + tr.off);
-        for (int i = tid + UL * (int)blockDim.x; i < n4; i += blockDim.x) adam4(gP[i], gG[i], gM[i], gV[i], i);
-    } else if (!GW) {
-        sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
-    }
+    if (!GW) sg_stage_commit<12>(Wimg, wv, a.params + tr.off + w_first, wfl / 4);
     __syncthreads();
     SG_PPO_STAMP(1);
     if (FUSED) {   // forward on this row group (a2c/model.py:255-264, a2c/distributions.py:109-118), activations stay in LDS
@@ -609,11 +548,8 @@ __global__ __launch_bounds__(512) void k_ppo_fwd_critic(PpoArgs a) {
 // parameters; its 4 waves each sum a quarter of the slabs (16 independent loads in flight per lane, i.e. two
 // round trips for 128 slabs instead of sixteen) and combine through LDS in a fixed order.
 #define SG_PPO_REDUCE_PARAMS 64
-// st != NULL (the two-launch step, Adam applied by the next k_ppo_bwd): this kernel also does what k_ppo_adam does beside Adam --
-// the step's loss sums into loss_acc (the same float product, the same double sum) and the NEXT step's bias corrections.
 __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_slabs, int slab_stride, int total,
-                                                    float* grad, float* part, SgOptState* st = nullptr, int k1 = 0, float inv_mb = 0.f,
-                                                    double* loss_acc = nullptr) {
+                                                    float* grad, float* part) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * SG_PPO_REDUCE_PARAMS + lane;
@@ -635,12 +571,10 @@ __global__ __launch_bounds__(256) void k_ppo_reduce(const float* slabs, int n_sl
     if (wave == 0) {
         g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         if (i < total + 8) grad[i] = g;
-        if (st && i >= total && i < total + 3) loss_acc[i - total] += (double)(g * inv_mb);
         float sq = (i < total) ? g * g : 0.f;
         sq = sg_wave_sum(sq);
         if (lane == 0) part[blockIdx.x] = sq;
     }
-    if (st && blockIdx.x == 0 && threadIdx.x == 64) sg_opt_prepare(st, st->t0 + k1 + 1);   // slot (t + 1) & 1: last read by the Adam of step t - 1, inside this step's k_ppo_bwd
 }
 
 // Adam scalars of the update's first step (every later step's are prepared by the preceding k_ppo_adam)
@@ -662,11 +596,7 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* grad, int total, flo
 __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float* v, const float* grad,
                                                   const float* part, int n_part, int total,
                                                   const SgOptState* st, int k1, float eps, float max_norm,
-                                                  float inv_mb, double* loss_acc, float* params_out = nullptr, float* m_out = nullptr,
-                                                  float* v_out = nullptr) {
-    // (out pointers: the last step of an update in the two-launch form reads one buffer set and writes the canonical one;
-    // NULL = in place.  loss_acc NULL: k_ppo_reduce has recorded the step's loss sums already.)
-    if (!params_out) { params_out = params; m_out = m; v_out = v; }
+                                                  float inv_mb, double* loss_acc) {
     __shared__ float s_coef;
     // Adam step t = st->t0 + k1; its bias-correction scalars were prepared in slot t & 1 by this step's k_ppo_bwd
     const int t = st->t0 + k1;
@@ -692,11 +622,11 @@ __global__ __launch_bounds__(256) void k_ppo_adam(float* params, float* m, float
         mi = mi + (g - mi) * (float)(1.0 - 0.9);
         vi = vi * (float)0.999 + (float)(1.0 - 0.999) * g * g;
         const float denom = sqrtf(vi) / s_bc2_sqrt + eps;
-        params_out[i] = params[i] - s_step_size * (mi / denom);
-        m_out[i] = mi;
-        v_out[i] = vi;
+        params[i] = params[i] - s_step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
     }
-    if (loss_acc && blockIdx.x == 0 && threadIdx.x < 3)  // value_loss.item() etc. are float32, summed in Python doubles
+    if (blockIdx.x == 0 && threadIdx.x < 3)  // value_loss.item() etc. are float32, summed in Python doubles
         loss_acc[threadIdx.x] += (double)(grad[total + threadIdx.x] * inv_mb);
     // the next step's bias corrections (double pow) into the other slot: nobody reads that slot before the next k_ppo_adam
     if (blockIdx.x == 0 && threadIdx.x == 64) sg_opt_prepare(const_cast<SgOptState*>(st), t + 1);

@@ -565,63 +565,3 @@ def test_one_row_group_minibatches_vs_oracle(world, c):
     assert_close(losses, olosses, what=f"{c['id']}: PPO losses of one update")
     assert_close_adam(pol.get_flat_params(), par, c["lr"], c["E"] * c["M"], what=f"{c['id']}: parameters after {c['E'] * c['M']} steps")
     assert np.abs(pol.get_flat_params() - p0).max() > 5 * c["lr"] * 0.5
-
-
-# ------------------------------------------------------- the PPO step as two launches (Adam applied by the next step's k_ppo_bwd)
-LAZY_CASES = [
-    dict(id="northstar", O=47, A=12, H=64, T=128, N=512, M=16, E=2, clip=0.2, lr=3e-4, ecoef=0.0),        # 4096-row minibatches, 128 row groups of 32
-    dict(id="refine", O=111, A=12, H=64, T=128, N=256, M=8, E=2, clip=0.1, lr=1.5e-4, ecoef=0.0),         # the 7-tile observation instance
-    dict(id="hopper_ppo", O=11, A=3, H=64, T=128, N=8, M=32, E=2, clip=0.2, lr=3e-4, ecoef=0.01),         # ONE 32-row group per trunk
-    dict(id="generic_h48", O=20, A=5, H=48, T=32, N=24, M=6, E=3, clip=0.1, lr=1e-3, ecoef=0.0),          # run-time-shape instance, 128-row steps
-    dict(id="wide_h96_rows16", O=60, A=6, H=96, T=16, N=8, M=8, E=2, clip=0.2, lr=3e-4, ecoef=0.0),       # 16-row steps on 256 threads: the trunk exceeds the register-held part
-    dict(id="ragged", O=47, A=12, H=64, T=9, N=13, M=4, E=2, clip=0.2, lr=3e-4, ecoef=0.0),               # 29-row minibatches, a dropped remainder
-]
-
-
-@pytest.mark.parametrize("c", LAZY_CASES, ids=[c["id"] for c in LAZY_CASES])
-def test_two_launch_ppo_step_is_bit_identical_to_three_launches(world, c):
-    """a2c/algo/ppo.py:143-145 (clip_grad_norm_ + optimizer.step) folded into the NEXT step's gradient launch (csrc/sg_ppo.hip: `lazy`)
-    against the three-launch step (k_ppo_bwd, k_ppo_reduce, k_ppo_adam): two updates of E x M steps from the same start with the
-    same permutations -- losses, parameters and both Adam moments EQUAL bit for bit, the step counter too; launch counts checked
-    (one k_ppo_adam per update instead of E x M)."""
-    import os
-    sg, lib, _lib = world["sg"], world["lib"], world["_lib"]
-    rng = np.random.default_rng(21)
-    Tc, Nc = c["T"], c["N"]
-    pol0 = sg.Policy((c["O"],), Box((c["A"],)), base_kwargs={"recurrent": False, "hidden_size": c["H"]}, seed=31)
-    ro = _filled_rollout(sg, lib, _lib, pol0, Tc, Nc, c["O"], c["A"], 4, 9)
-    p0 = (pol0.get_flat_params() + 0.01 * rng.standard_normal(pol0.num_params)).astype(np.float32)
-    perms = [np.stack([rng.permutation(Tc * Nc) for _ in range(c["E"])]).astype(np.int64) for _ in range(2)]
-
-    def run(lazy):
-        old = os.environ.get("SG_PPO_LAZY")
-        os.environ["SG_PPO_LAZY"] = "1" if lazy else "0"
-        try:
-            pol = sg.Policy((c["O"],), Box((c["A"],)), base_kwargs={"recurrent": False, "hidden_size": c["H"]}, seed=31)
-            pol.set_flat_params(p0)
-            agent = sg.algo.PPO(pol, c["clip"], c["E"], c["M"], 0.5, c["ecoef"], lr=c["lr"], eps=1e-5, max_grad_norm=0.5)
-            losses = [agent.update(ro, perms=perms[u]) for u in range(2)]
-            m, v, t = agent.get_adam()
-            p_end = pol.get_flat_params()
-            ctx = pol.ctx
-            ctx.profile_reset()
-            ctx.profile(True)
-            agent.update(ro, perms=perms[0])           # a direct-launch pass with HIP events: the graphs are bypassed, the mode is the same
-            ctx.profile(False)
-            launches = {"bwd": ctx.profile_read(3)[1], "reduce": ctx.profile_read(4)[1], "adam": ctx.profile_read(6)[1]}
-            return np.asarray(losses, np.float64), p_end, m, v, t, launches
-        finally:
-            if old is None:
-                os.environ.pop("SG_PPO_LAZY", None)
-            else:
-                os.environ["SG_PPO_LAZY"] = old
-
-    a, b = run(True), run(False)
-    steps = c["E"] * c["M"]
-    assert a[4] == b[4] == 2 * steps
-    assert a[5] == {"bwd": steps, "reduce": steps, "adam": 1}, f"the two-launch step did not run: {a[5]}"
-    assert b[5] == {"bwd": steps, "reduce": steps, "adam": steps}, b[5]
-    assert np.array_equal(a[0], b[0]), (a[0], b[0])
-    for what, x, y in (("parameters", a[1], b[1]), ("Adam m", a[2], b[2]), ("Adam v", a[3], b[3])):
-        assert np.array_equal(x, y), f"{c['id']}: {what} differ in {int((x != y).sum())} of {x.size} entries, worst {np.abs(x - y).max():.3e}"
-    assert np.abs(a[1] - p0).max() > 5 * c["lr"] * 0.5

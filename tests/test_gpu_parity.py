@@ -873,7 +873,7 @@ def test_injected_draws_are_validated(sg):
     assert a_ == b_ and np.array_equal(D.get_flat_params(), D2.get_flat_params())
 
 
-KNOBS = [{"SG_PPO_FUSED": "0"}, {"SG_PPO_LAZY": "0"}, {"SG_PPO_ROWS": "16"}, {"SG_PPO_ROWS": "32"}, {"SG_PPO_WAVES": "4"}, {"SG_DISC_CHAIN": "wide"},
+KNOBS = [{"SG_PPO_FUSED": "0"}, {"SG_PPO_ROWS": "16"}, {"SG_PPO_ROWS": "32"}, {"SG_PPO_WAVES": "4"}, {"SG_DISC_CHAIN": "wide"},
          {"SG_PPO_GRAPH": "0", "SG_DISC_GRAPH": "0"}, {"SG_WGRAD_XCD": "0"}]
 
 
