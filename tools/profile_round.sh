@@ -19,7 +19,7 @@ bash tools/profile_calibration.sh $tag 1024 > $out/${tag}_calibration.log 2>&1
 for n in 2 8; do
     timeout 900 python bench.py --gpus $n --loopback --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_loopback_n$n.json 2> $out/${tag}_bench_loopback_n$n.err
 done
-SG_PARITY_RECORD=$out/${tag}_benchpath_parity.json SG_STEPLOCK_RECORD=$out/${tag}_parity.json timeout 2400 python -m pytest tests -m gpu -q --durations=15 2>&1 | tail -60 > $out/${tag}_pytest_gpu.txt
+SG_PARITY_RECORD=$out/${tag}_benchpath_parity.json SG_STEPLOCK_RECORD=$out/${tag}_parity.json SG_PARITY_F64_RECORD=$out/${tag}_parity_f64.json timeout 3000 python -m pytest tests -m gpu -q --durations=15 2>&1 | tail -60 > $out/${tag}_pytest_gpu.txt
 rm -f $out/${tag}_*_profile.log $out/${tag}_*_counters.log $out/${tag}_calibration.log $out/${tag}_*.err
 tail -3 $out/${tag}_pytest_gpu.txt
 for w in northstar hopper laikago refine hopper_ppo; do head -9 $out/${tag}_${w}_kernel_trace.txt | tail -6; cut -c1-160 $out/${tag}_${w}_bench.json; done
