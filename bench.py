@@ -19,6 +19,13 @@ all-reduce) on RCCL inside the library.  Either launched by torch.distributed.ru
 or plainly as `python bench.py --gpus N`: it then starts the N ranks itself (the same torch.distributed.run command),
 forwards rank 0's line and returns non-zero if any rank failed.  Prints ONE JSON line on rank 0.
 
+The line is COMPACT (about 1.7 KB, `compact_line`): every key of the driver's contract, the dominant kernel's roofline (HIP-event
+and rocprofv3 clocks, counter traffic, SQ MFMA-busy), the whole update's MFMA / HBM fractions, the CPU baseline, one
+[ms, env-steps/s, frac, MFMA-busy] quadruple per other BASELINE.json configuration, the drop-in legs, and for N > 1 the comm block
+(which discriminator mode ran, the other mode's value, both all-reduce forms).  The FULL record -- per-kernel tables, spreads,
+sample descriptions, per-rank lists -- is written to gpurun_out/bench_full_<workload>_n<N>.json (named in the line as
+`full_record`) and to stderr; `--full-line` prints it on stdout instead.
+
 `--loopback` (self-test of the N > 1 path on a box with fewer than N GPUs): the ranks share the visible device(s) and use
 the library's shared-memory loopback communicator instead of RCCL; the line says so and is not a scaling measurement.
 """
