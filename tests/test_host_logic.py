@@ -1,6 +1,7 @@
 """CPU: host-side logic around the hot path -- the drop-in import surface (alias modules), the environment-pool shard
 with VecNormalize's return scaling against a reference-generated fixture, and checkpoint-reading safety.  No GPU, no
 compute entry point of libsimgan_hip.so is called."""
+import json
 import os
 import pickle
 import subprocess
@@ -335,3 +336,65 @@ def test_mod_reward_walks_back_from_the_cursor_with_wrap_around():
             want[t, :, 0] += off
         got = ro.rewards.numpy() if hasattr(ro.rewards, "numpy") else ro.rewards
         assert np.array_equal(got, want), (step, back)
+
+
+# --------------------------------------------------------------------------------------- bench.py's stdout line
+def test_bench_compact_line_keeps_the_contract_and_fits_a_2kb_tail():
+    """The driver keeps 2,000 characters of stdout and the contract's keys: the compact line (bench.compact_line) must carry every
+    contract key, the per-configuration numbers and the roofline / CPU-baseline objects inside that budget, for the N = 1 record
+    of the driver's own command and for an N = 8 record (comm block, per-rank list, replica check)."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_v27_northstar_bench_full.json")))
+    c = bench.compact_line(full, "gpurun_out/bench_full_northstar_n1.json")
+    line = json.dumps(c)
+    assert len(line) < 2000, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline", "full_record"):
+        assert k in c, k
+    assert c["value"] == full["value"] and c["ms_per_step"] == full["ms_per_step"] and c["vs_baseline"] is None
+    assert c["config"]["workload"].startswith("northstar") and len(c["config"]["workload"]) <= 120
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "k_disc_step4" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 0.0 < r["mfma_busy"] < 1.0 and r["traffic"] > 1e6 and r["traffic_stale"] is False and r["counters_stale"] is False
+    assert set(c["other_workloads_ms_envsteps_frac_busy"]) == {"hopper", "laikago", "refine", "hopper_ppo"}
+    assert all(len(v) == 4 and v[0] > 0 for v in c["other_workloads_ms_envsteps_frac_busy"].values())
+    assert c["dropin_ms"]["literal_main"] == full["dropin"]["literal_main"]["ms_per_step"]
+    cb = c["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores_value"] > cb["value"] and cb["unit"] == "env-steps/s"
+    # an N = 8 record: the driver's scaling run
+    full8 = dict(full, n_gpus=8, per_rank_ms_per_step=[26.3] * 8, replica_check={"ok": True, "weights_sha256_rank0": "0" * 16, "ranks": 8},
+                 comm={"kind": "rccl", "nranks_reported_by_rccl": 8, "disc_mode": "replicated", "peer_allreduce": False, "allreduce_us": 12.3,
+                       "allreduce_count_per_update": 160, "allreduce_form": "rccl", "backend": "x" * 300,
+                       "disc_other_mode": {"mode": "sharded", "steps": 10, "ms_per_step": 80.0, "value": 6.5e6, "per_rank_ms_per_step": [80.0] * 8},
+                       "peer": {"form": "peer mesh", "steps": 10, "ms_per_step": 40.0, "value": 1.3e7, "allreduce_us": 9.0, "per_rank_ms_per_step": [40.0] * 8}})
+    full8.pop("other_workloads", None); full8.pop("dropin", None); full8.pop("cpu_baseline", None)
+    c8 = bench.compact_line(full8, None)
+    assert len(json.dumps(c8)) < 2000
+    assert c8["comm"]["disc_mode"] == "replicated" and c8["comm"]["disc_other_mode"] == {"mode": "sharded", "value": 6.5e6, "ms_per_step": 80.0}
+    assert c8["comm"]["peer"]["allreduce_us"] == 9.0 and len(c8["per_rank_ms_per_step"]) == 8 and c8["replica_check"]["ok"] is True
+    assert "last_losses" in c8 and "full_record" not in c8
+    # an error line (watchdog before the headline): value null, the error and the ranks' stages survive
+    e = bench.compact_line({"metric": "m", "value": None, "unit": "env-steps/s", "n_gpus": 8, "steps": 1, "warmup": 1, "higher_is_better": True, "scaling": "weak",
+                            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "northstar"}, "ms_per_step": None,
+                            "error": "watchdog: no progress", "stage": "init: communicator", "ranks": {"0": "x"}, "elapsed_s": 31.0})
+    assert e["value"] is None and e["error"].startswith("watchdog") and e["stage"] and e["ranks"] == {"0": "x"}
+
+
+def test_counter_summary_is_reproducible_from_the_committed_passes(tmp_path):
+    """profiles/counters.json (what bench.py reads for roofline.mfma_busy) is tools/make_counters.py run on the committed
+    per-pass summaries: re-derive the dominant kernels' MFMA-busy fractions from the raw counter lines."""
+    import re
+    doc = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    tag = doc["tag"]
+    assert set(doc["workloads"]) == {"northstar", "hopper", "laikago", "refine", "hopper_ppo"}
+    for wl, kern in (("northstar", "k_disc_step4"), ("refine", "k_ppo_bwd")):
+        vals = {}
+        for line in open(os.path.join(ROOT, "profiles", f"{tag}_{wl}_pmc_sq_mfma.txt")):
+            m = re.match(r"(?:void )?(\w+)(?:<[^>]*>)?\s+(\w+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if m and m.group(1) == kern:
+                vals[m.group(2)] = (float(m.group(4)), float(m.group(6)))
+        busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (vals["SQ_BUSY_CYCLES"][1] * 1024)
+        d = doc["workloads"][wl]["kernels"][kern]["derived"]
+        assert abs(d["mfma_busy"] - busy) < 1e-4, (wl, d["mfma_busy"], busy)
+        assert 0.5 < d["wave_wait"] + d["wave_issue_stall"] + d["wave_active"] <= 1.01
+        assert d["mfma_flops"] > 0 and doc["workloads"][wl]["lib_sha256"]
