@@ -70,8 +70,13 @@ __device__ __forceinline__ void sg4_load_a(float4 (&a)[RG][SG4_NCH(K)], const fl
         }
 }
 
+#ifndef SG4_TIMING_SKIP
+#define SG4_TIMING_SKIP 0        // diagnostic builds (WRONG results, timing only): 1 = every other group of four MFMAs is not issued
+#endif
 #define SG4_STEP(CC)                                                                 \
-    if (4 * tc + (CC) < SG4_NW(K)) {                                                 \
+    if (SG4_TIMING_SKIP && ((CC) & 1)) {   /* the registers stay loaded, the MFMAs are not issued */ \
+        if (4 * tc + (CC) < SG4_NW(K)) { const float4 wk = w[4 * tc + (CC) < SG4_NW(K) ? 4 * tc + (CC) : 0]; asm volatile("" ::"v"(wk.x), "v"(wk.y), "v"(wk.z), "v"(wk.w)); } \
+    } else if (4 * tc + (CC) < SG4_NW(K)) {                                          \
         const float4 wq = w[4 * tc + (CC) < SG4_NW(K) ? 4 * tc + (CC) : 0];          \
         _Pragma("unroll") for (int rg = 0; rg < RG; ++rg) {                          \
             acc[rg][0] = sg4_mfma<CC>(a[rg][tc].x, wq.x, acc[rg][0]);                \
